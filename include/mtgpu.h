@@ -1,0 +1,143 @@
+/*
+ * mtgpu.h — C ABI of the MI355X (gfx950) motion-vector scanner.
+ *
+ * Drop-in boundary for ONE path of Vaibhav-20022002/Motion-Estimated-Video-Trimmer:
+ * the per-frame MV scan (MotionScanner::check_frame) and the gap-bounded segment
+ * merge.  The reference has no FFI for this path (it is plain C++ inside one
+ * static library); every entry point below names the reference
+ * code it replaces (file:line in the reference tree).  Plain pointers and sizes
+ * only; no C++ or torch types cross this boundary.  INTEGRATION.md shows the
+ * adapter a maintainer adds on the reference side.
+ *
+ * Conventions
+ *  - every function returns an MT_* status (0 = ok), never throws, and may be
+ *    called from many host threads (the reference enters the scanner from
+ *    N workers x S streams: src/pipeline.cpp:186-197, src/batch_processor.cpp:152-157);
+ *  - `*_device` entry points take DEVICE pointers and a hipStream_t passed as
+ *    `void *stream` (NULL = the default stream) and are asynchronous on it
+ *    unless stated; the others take HOST pointers and are synchronous;
+ *  - a batch of frames is CSR: frame f owns records [frame_off[f], frame_off[f+1])
+ *    of one packed array of 40-byte AVMotionVector records (mt_mv).  The bytes
+ *    are copied / consumed at call time, as the MV side data of an AVFrame dies
+ *    when the frame is reused (src/motion_scanner.cpp:347);
+ *  - there is NO CPU fallback: if no gfx950 device is usable every compute entry
+ *    point fails with MT_ERR_DEVICE.
+ */
+#ifndef MTGPU_H
+#define MTGPU_H
+
+#include "mt_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mtgpu_ctx mtgpu_ctx;
+
+/* Library identification string. */
+const char *mtgpu_version(void);
+
+/* Last error message of the calling thread ("" if none). Replaces the reference's
+ * LOG_ERROR lines (src/motion_scanner.cpp:66-177). */
+const char *mtgpu_last_error(void);
+
+/* Number of usable HIP devices (0 if none / no driver). Host-side analogue of
+ * get_available_cpus() for the stream->GPU assignment (src/system.cpp:166-184). */
+int mtgpu_device_count(void);
+
+/*
+ * Derive the parameter block exactly as MotionScanner::initialize() does
+ * (src/motion_scanner.cpp:184-199; defaults include/motion_trim/config.hpp:56-89):
+ *   grid_w/h = int16((dim + block_size - 1) >> block_shift),
+ *   vertical_margin = int(float(grid_h) * vertical_mask)   [float32 product],
+ *   vectors_needed = uint8(vectors_needed).
+ * Pure host arithmetic; no device needed.
+ */
+int mtgpu_params_from_config(mt_scan_params *out, int width, int height,
+                             double mv_threshold_sq, int block_size, int block_shift,
+                             int vectors_needed, int clusters_needed, float vertical_mask);
+
+/*
+ * Create / destroy a scanner context bound to one device.  Replaces the
+ * per-worker `MotionScanner` instance's scan state (cfg + grid_votes,
+ * include/motion_trim/motion_scanner.hpp:75-93): the vote grid now lives in LDS,
+ * the context only holds the validated parameters, the launch plan and a
+ * private stream + staging buffers for the host-pointer entry points.
+ */
+int mtgpu_create(const mt_scan_params *params, int device, mtgpu_ctx **out);
+void mtgpu_destroy(mtgpu_ctx *ctx);
+int mtgpu_get_params(const mtgpu_ctx *ctx, mt_scan_params *out);
+
+/* Launch plan chosen for the context's grid (for reports and tests). */
+typedef struct mtgpu_plan {
+  int32_t block_threads;   /* workgroup size                                      */
+  int32_t bands;           /* row bands per frame (1 = whole grid in one LDS tile) */
+  int32_t band_rows;       /* analysed rows per band                               */
+  int32_t lds_bytes;       /* dynamic LDS per workgroup                            */
+  int32_t counter_bits;    /* width of one LDS vote counter                        */
+  int32_t device;
+  int32_t cu_count;
+  int32_t _pad;
+} mtgpu_plan;
+int mtgpu_get_plan(const mtgpu_ctx *ctx, mtgpu_plan *out);
+
+/*
+ * check_frame() over a device-resident batch — replaces the per-frame call at
+ * src/motion_scanner.cpp:376 (body :217-295).
+ *   d_mv         packed mt_mv records, n_records of them (device)
+ *   d_frame_off  n_frames+1 record offsets (device); entries are clamped to n_records
+ *   d_has_sd     optional (device, may be NULL): has_sd[f]==0 <=> the frame had no
+ *                AV_FRAME_DATA_MOTION_VECTORS side data (-> false, :219-221).
+ *                NULL: a frame has side data iff it owns >= 1 record.
+ *   d_flags      n_frames bytes (device): 1 = significant motion, 0 = none
+ * Asynchronous on `stream`.
+ */
+int mtgpu_scan_frames_device(mtgpu_ctx *ctx, const void *d_mv, uint64_t n_records,
+                             const uint64_t *d_frame_off, const uint8_t *d_has_sd,
+                             uint32_t n_frames, uint8_t *d_flags, void *stream);
+
+/* Same for HOST pointers: validates frame_off, copies the batch to the device,
+ * scans, copies the flags back, synchronous.  This is the call an adapter makes
+ * after copying each AVFrame's side data into a batch. */
+int mtgpu_scan_frames(mtgpu_ctx *ctx, const mt_mv *mv, const uint64_t *frame_off,
+                      const uint8_t *has_sd, uint32_t n_frames, uint8_t *flags);
+
+/*
+ * Segment merge — replaces src/pipeline.cpp:302-358, 387-388 (std::sort +
+ * std::unique of the pooled motion timestamps, the gap-bounded merge, the clamp,
+ * the savings and the cut decision).  Runs on the device.
+ *   ts            n motion timestamps in ANY order, duplicates allowed (host)
+ *   job_semantics 0: `out` = merged, clamped segments; 1: what FFmpegJob::segments
+ *                 would carry (full-copy segment {0,duration} when the savings are
+ *                 too low; nothing when there was no motion)
+ *   out/cap       host array; MT_ERR_CAPACITY if too small (res->n_segments = need)
+ */
+int mtgpu_merge_segments(mtgpu_ctx *ctx, const double *ts, uint64_t n,
+                         const mt_merge_params *mp, int job_semantics,
+                         mt_segment *out, uint64_t cap, mt_merge_result *res);
+
+/*
+ * Streams on the device, end to end: for S independent streams whose frames sit
+ * contiguously in one batch (stream s owns frames [stream_off[s], stream_off[s+1])),
+ * turn per-frame flags + per-frame pts into per-stream segment lists without
+ * leaving the device: compaction (src/motion_scanner.cpp:382-383), sort+unique
+ * (src/pipeline.cpp:302-304), merge/clamp/savings/decision (:323-358, 387-388).
+ *   d_flags       n_frames bytes from mtgpu_scan_frames_device
+ *   d_pts         n_frames doubles: pts of each frame in seconds (:361)
+ *   d_stream_off  S+1 frame offsets (device)
+ *   d_mp          S merge-parameter blocks (device)
+ *   d_ts          workspace, n_frames doubles (device): compacted timestamps, stream-major
+ *   d_seg         S * seg_cap segments (device): stream s writes at d_seg[s*seg_cap]
+ *   d_res         S results (device); n_segments > seg_cap signals truncation
+ * Asynchronous on `stream`.
+ */
+int mtgpu_merge_streams_device(mtgpu_ctx *ctx, const uint8_t *d_flags, const double *d_pts,
+                               const uint64_t *d_stream_off, uint32_t n_streams,
+                               const mt_merge_params *d_mp, int job_semantics,
+                               double *d_ts, mt_segment *d_seg, uint64_t seg_cap,
+                               mt_merge_result *d_res, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MTGPU_H */

@@ -1,0 +1,381 @@
+// mtgpu_api.hip — implementation of the C ABI declared in include/mtgpu.h:
+// parameter derivation, launch planning, host<->device staging.  The compute is
+// in scan_kernels.hip / merge_kernels.hip; nothing here computes a result on
+// the CPU (no fallback: without a usable device every compute call fails).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+
+#include "../../include/mtgpu.h"
+#include "merge_kernels.h"
+#include "scan_kernels.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+int hip_fail(hipError_t e, const char *what) {
+  return fail(MT_ERR_DEVICE, "%s: %s", what, hipGetErrorString(e));
+}
+
+#define HIP_TRY(expr)                                   \
+  do {                                                  \
+    hipError_t _e = (expr);                             \
+    if (_e != hipSuccess) return hip_fail(_e, #expr);   \
+  } while (0)
+
+// Grow-only device buffer used by the host-pointer entry points.
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  int reserve(size_t bytes) {
+    if (bytes <= cap) return MT_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr; cap = 0;
+    size_t want = bytes + bytes / 4 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) { p = nullptr; return hip_fail(e, "hipMalloc(staging)"); }
+    cap = want;
+    return MT_OK;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+}  // namespace
+
+struct mtgpu_ctx {
+  mt_scan_params params;
+  mtgpu::ScanK k;
+  mtgpu_plan plan;
+  int device;
+  hipStream_t stream;    // private stream of the host-pointer entry points
+  std::mutex mu;         // guards the staging buffers below
+  DevBuf d_mv, d_off, d_sd, d_flags, d_misc;
+};
+
+namespace {
+
+// keep an MV iff !(mag_sq < T) with mag_sq a non-negative integer (src/motion_scanner.cpp:251)
+//   <=>  mag_sq >= ceil(T)   (T NaN or <= 0: keep all;  T above any reachable mag_sq: keep none)
+unsigned long long threshold_to_int(double t) {
+  if (!(t > 0.0)) return 0ull;                       // NaN, 0, negative
+  if (t > 17179869184.0) return ~0ull;               // > 2^34 > 2 * 65535^2: unreachable
+  return (unsigned long long)std::ceil(t);
+}
+
+int validate_params(const mt_scan_params *p) {
+  if (!p) return fail(MT_ERR_INVALID, "params is NULL");
+  if (p->grid_w < 1 || p->grid_h < 1 || p->grid_w > 32767 || p->grid_h > 32767)
+    return fail(MT_ERR_INVALID, "grid %dx%d outside [1,32767] (int16 in the reference)", p->grid_w, p->grid_h);
+  if (p->block_shift < 0 || p->block_shift > 31)
+    return fail(MT_ERR_INVALID, "block_shift %d outside [0,31]", p->block_shift);
+  if (p->vertical_margin < 0)
+    return fail(MT_ERR_INVALID, "vertical_margin %d < 0 (the reference would index before the grid)", p->vertical_margin);
+  return MT_OK;
+}
+
+size_t lds_need(int rows, int gw, int W, int *cnt_words) {
+  size_t cw = ((size_t)(rows + 2) * (size_t)gw + 3u) & ~(size_t)3u;
+  if (cnt_words) *cnt_words = (int)cw;
+  return cw * 4u + (size_t)(rows + 2) * (size_t)W * 8u + 16u;
+}
+
+int make_plan(mtgpu_ctx *c, int lds_max, int cu_count) {
+  const mt_scan_params &p = c->params;
+  mtgpu::ScanK &k = c->k;
+  k.thr = threshold_to_int(p.mv_threshold_sq);
+  k.shift = p.block_shift;
+  k.gw = p.grid_w;
+  k.gh = p.grid_h;
+  k.y_lo = p.vertical_margin;                                // :237
+  k.y_hi = p.grid_h - p.vertical_margin;                     // :238
+  if (k.y_hi < k.y_lo) k.y_hi = k.y_lo;                      // empty analysed range
+  k.vec_need = p.vectors_needed;
+  k.clust_need = p.clusters_needed < 1 ? 1u : (unsigned int)p.clusters_needed;
+  k.W = (p.grid_w + 63) / 64;
+  const int R = k.y_hi - k.y_lo;
+  int rows = R < 1 ? 1 : R;
+  if (lds_need(rows, k.gw, k.W, nullptr) > (size_t)lds_max) {
+    // largest band that fits: need(r) is linear in r
+    const size_t per_row = (size_t)k.gw * 4u + (size_t)k.W * 8u;
+    long r = ((long)lds_max - 16 - 16) / (long)per_row - 2;
+    while (r >= 1 && lds_need((int)r, k.gw, k.W, nullptr) > (size_t)lds_max) --r;
+    if (r < 1)
+      return fail(MT_ERR_CAPACITY, "grid width %d: three counter rows do not fit %d bytes of LDS", k.gw, lds_max);
+    rows = (int)r;
+  }
+  k.band_rows = rows;
+  k.bands = R < 1 ? 1 : (R + rows - 1) / rows;
+  k.mask_rows = rows + 2;
+  const size_t lds = lds_need(rows, k.gw, k.W, &k.cnt_words);
+  c->plan.block_threads = lds <= 40u * 1024u ? 256 : (lds <= 80u * 1024u ? 512 : 1024);
+  c->plan.bands = k.bands;
+  c->plan.band_rows = k.band_rows;
+  c->plan.lds_bytes = (int)lds;
+  c->plan.counter_bits = 32;
+  c->plan.device = c->device;
+  c->plan.cu_count = cu_count;
+  c->plan._pad = 0;
+  return MT_OK;
+}
+
+int launch_scan_on(mtgpu_ctx *c, const void *d_mv, uint64_t n_records, const uint64_t *d_off,
+                   const uint8_t *d_sd, uint32_t n_frames, uint8_t *d_flags, unsigned int *d_centres,
+                   hipStream_t st) {
+  mtgpu::ScanLaunch L;
+  L.mv = static_cast<const unsigned char *>(d_mv);
+  L.n_records = n_records;
+  L.frame_off = reinterpret_cast<const unsigned long long *>(d_off);
+  L.has_sd = d_sd;
+  L.n_frames = n_frames;
+  L.flags = d_flags;
+  L.frame_centres = d_centres;
+  L.k = c->k;
+  L.block = c->plan.block_threads;
+  L.lds_bytes = c->plan.lds_bytes;
+  L.stream = st;
+  hipError_t e = mtgpu::launch_scan(L);
+  if (e != hipSuccess) return hip_fail(e, "scan launch");
+  return MT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *mtgpu_version(void) { return "mtgpu 0.1 (gfx950 MV scan + segment merge)"; }
+
+const char *mtgpu_last_error(void) { return g_err; }
+
+int mtgpu_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int mtgpu_params_from_config(mt_scan_params *out, int width, int height, double mv_threshold_sq,
+                             int block_size, int block_shift, int vectors_needed,
+                             int clusters_needed, float vertical_mask) {
+  if (!out) return fail(MT_ERR_INVALID, "out is NULL");
+  if (block_shift < 0 || block_shift > 31) return fail(MT_ERR_INVALID, "block_shift %d outside [0,31]", block_shift);
+  // src/motion_scanner.cpp:190-193
+  const long long gw = ((long long)width + block_size - 1) >> block_shift;
+  const long long gh = ((long long)height + block_size - 1) >> block_shift;
+  if (gw < 1 || gh < 1 || gw > 32767 || gh > 32767)
+    return fail(MT_ERR_INVALID, "grid %lldx%lld outside [1,32767]", gw, gh);
+  std::memset(out, 0, sizeof *out);
+  out->mv_threshold_sq = mv_threshold_sq;              // :184
+  out->block_shift = block_shift;                      // :185
+  out->vectors_needed = (uint8_t)vectors_needed;       // :186, config.hpp:75
+  out->clusters_needed = clusters_needed;              // :187
+  out->grid_w = (int32_t)gw;
+  out->grid_h = (int32_t)gh;
+  const float margin = (float)(int16_t)gh * vertical_mask;   // :196, float32 product
+  out->vertical_margin = (int)margin;
+  return MT_OK;
+}
+
+int mtgpu_create(const mt_scan_params *params, int device, mtgpu_ctx **out) {
+  if (!out) return fail(MT_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  int rc = validate_params(params);
+  if (rc != MT_OK) return rc;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev < 1)
+    return fail(MT_ERR_DEVICE, "no HIP device available (%s); this library has no CPU fallback",
+                e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+  if (device < 0 || device >= ndev) return fail(MT_ERR_INVALID, "device %d outside [0,%d)", device, ndev);
+  HIP_TRY(hipSetDevice(device));
+  int lds_max = 0, cus = 0;
+  HIP_TRY(hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, device));
+  HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+  mtgpu_ctx *c = new (std::nothrow) mtgpu_ctx();
+  if (!c) return fail(MT_ERR_NOMEM, "out of host memory");
+  c->params = *params;
+  c->device = device;
+  c->stream = nullptr;
+  rc = make_plan(c, lds_max, cus);
+  if (rc != MT_OK) { delete c; return rc; }
+  e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) { delete c; return hip_fail(e, "hipStreamCreate"); }
+  *out = c;
+  return MT_OK;
+}
+
+void mtgpu_destroy(mtgpu_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+  c->d_mv.release(); c->d_off.release(); c->d_sd.release(); c->d_flags.release(); c->d_misc.release();
+  delete c;
+}
+
+int mtgpu_get_params(const mtgpu_ctx *c, mt_scan_params *out) {
+  if (!c || !out) return fail(MT_ERR_INVALID, "NULL argument");
+  *out = c->params;
+  return MT_OK;
+}
+
+int mtgpu_get_plan(const mtgpu_ctx *c, mtgpu_plan *out) {
+  if (!c || !out) return fail(MT_ERR_INVALID, "NULL argument");
+  *out = c->plan;
+  return MT_OK;
+}
+
+int mtgpu_scan_frames_device(mtgpu_ctx *c, const void *d_mv, uint64_t n_records,
+                             const uint64_t *d_frame_off, const uint8_t *d_has_sd,
+                             uint32_t n_frames, uint8_t *d_flags, void *stream) {
+  if (!c) return fail(MT_ERR_INVALID, "ctx is NULL");
+  if (n_frames == 0) return MT_OK;
+  if (!d_frame_off || !d_flags) return fail(MT_ERR_INVALID, "frame_off/flags is NULL");
+  if (n_records > 0 && !d_mv) return fail(MT_ERR_INVALID, "mv is NULL with n_records > 0");
+  if (((uintptr_t)d_mv & 3u) != 0) return fail(MT_ERR_INVALID, "mv must be 4-byte aligned");
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  unsigned int *centres = nullptr;
+  if (c->k.bands > 1)
+    HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&centres), sizeof(unsigned int) * (size_t)n_frames, st));
+  int rc = launch_scan_on(c, d_mv, n_records, d_frame_off, d_has_sd, n_frames, d_flags, centres, st);
+  if (centres) {
+    hipError_t e = hipFreeAsync(centres, st);
+    if (rc == MT_OK && e != hipSuccess) rc = hip_fail(e, "hipFreeAsync");
+  }
+  return rc;
+}
+
+int mtgpu_scan_frames(mtgpu_ctx *c, const mt_mv *mv, const uint64_t *frame_off,
+                      const uint8_t *has_sd, uint32_t n_frames, uint8_t *flags) {
+  if (!c) return fail(MT_ERR_INVALID, "ctx is NULL");
+  if (n_frames == 0) return MT_OK;
+  if (!frame_off || !flags) return fail(MT_ERR_INVALID, "frame_off/flags is NULL");
+  for (uint32_t f = 0; f < n_frames; ++f)
+    if (frame_off[f + 1] < frame_off[f])
+      return fail(MT_ERR_INVALID, "frame_off not monotonic at frame %u", f);
+  const uint64_t r_begin = frame_off[0], r_end = frame_off[n_frames];
+  const uint64_t n_records = r_end - r_begin;
+  if (n_records > 0 && !mv) return fail(MT_ERR_INVALID, "mv is NULL with records present");
+
+  std::lock_guard<std::mutex> lock(c->mu);
+  HIP_TRY(hipSetDevice(c->device));
+  int rc;
+  if ((rc = c->d_mv.reserve((size_t)n_records * MT_MV_BYTES + 16)) != MT_OK) return rc;
+  if ((rc = c->d_off.reserve(sizeof(uint64_t) * ((size_t)n_frames + 1))) != MT_OK) return rc;
+  if ((rc = c->d_flags.reserve(n_frames)) != MT_OK) return rc;
+  if (has_sd && (rc = c->d_sd.reserve(n_frames)) != MT_OK) return rc;
+  if (c->k.bands > 1 && (rc = c->d_misc.reserve(sizeof(unsigned int) * (size_t)n_frames)) != MT_OK) return rc;
+
+  hipStream_t st = c->stream;
+  if (n_records)
+    HIP_TRY(hipMemcpyAsync(c->d_mv.p, mv + r_begin, (size_t)n_records * MT_MV_BYTES, hipMemcpyHostToDevice, st));
+  // offsets are rebased to the copied window on the device side by passing a shifted base
+  HIP_TRY(hipMemcpyAsync(c->d_off.p, frame_off, sizeof(uint64_t) * ((size_t)n_frames + 1), hipMemcpyHostToDevice, st));
+  if (has_sd) HIP_TRY(hipMemcpyAsync(c->d_sd.p, has_sd, n_frames, hipMemcpyHostToDevice, st));
+  // records of frame f live at d_mv + (frame_off[f] - r_begin) * 40: shift the base pointer
+  const unsigned char *base = static_cast<const unsigned char *>(c->d_mv.p) - (size_t)r_begin * MT_MV_BYTES;
+  rc = launch_scan_on(c, base, r_end, static_cast<const uint64_t *>(c->d_off.p),
+                      has_sd ? static_cast<const uint8_t *>(c->d_sd.p) : nullptr, n_frames,
+                      static_cast<uint8_t *>(c->d_flags.p), static_cast<unsigned int *>(c->d_misc.p), st);
+  if (rc != MT_OK) return rc;
+  HIP_TRY(hipMemcpyAsync(flags, c->d_flags.p, n_frames, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return MT_OK;
+}
+
+int mtgpu_merge_streams_device(mtgpu_ctx *c, const uint8_t *d_flags, const double *d_pts,
+                               const uint64_t *d_stream_off, uint32_t n_streams,
+                               const mt_merge_params *d_mp, int job_semantics, double *d_ts,
+                               mt_segment *d_seg, uint64_t seg_cap, mt_merge_result *d_res,
+                               void *stream) {
+  if (!c) return fail(MT_ERR_INVALID, "ctx is NULL");
+  if (n_streams == 0) return MT_OK;
+  if (!d_pts || !d_stream_off || !d_mp || !d_ts || !d_res || (seg_cap && !d_seg))
+    return fail(MT_ERR_INVALID, "NULL device pointer");
+  HIP_TRY(hipSetDevice(c->device));
+  mtgpu::MergeLaunch L;
+  L.flags = d_flags;
+  L.pts = d_pts;
+  L.stream_off = reinterpret_cast<const unsigned long long *>(d_stream_off);
+  L.n_frames_total = ~0ull;   // stream_off is trusted to lie inside the caller's arrays
+  L.mp = d_mp;
+  L.job_semantics = job_semantics;
+  L.ts_ws = d_ts;
+  L.seg = d_seg;
+  L.seg_cap = seg_cap;
+  L.res = d_res;
+  L.n_streams = n_streams;
+  L.stream = static_cast<hipStream_t>(stream);
+  hipError_t e = mtgpu::launch_merge(L);
+  if (e != hipSuccess) return hip_fail(e, "merge launch");
+  return MT_OK;
+}
+
+int mtgpu_merge_segments(mtgpu_ctx *c, const double *ts, uint64_t n, const mt_merge_params *mp,
+                         int job_semantics, mt_segment *out, uint64_t cap, mt_merge_result *res) {
+  if (!c) return fail(MT_ERR_INVALID, "ctx is NULL");
+  if (!mp || !res) return fail(MT_ERR_INVALID, "mp/res is NULL");
+  if (n > 0 && !ts) return fail(MT_ERR_INVALID, "ts is NULL with n > 0");
+  if (cap > 0 && !out) return fail(MT_ERR_INVALID, "out is NULL with cap > 0");
+
+  std::lock_guard<std::mutex> lock(c->mu);
+  HIP_TRY(hipSetDevice(c->device));
+  // one staging block: pts[n] | ws[2n] | seg[segs] | off[2] | mp | res
+  const uint64_t segs = (cap < n ? cap : n) + 1;        // K <= n; +1 for the full-copy segment
+  size_t o_pts = 0;
+  size_t o_ws = o_pts + sizeof(double) * (size_t)n;
+  size_t o_seg = o_ws + sizeof(double) * 2 * (size_t)n;
+  size_t o_off = o_seg + sizeof(mt_segment) * (size_t)segs;
+  size_t o_mp = o_off + sizeof(uint64_t) * 2;
+  size_t o_res = o_mp + sizeof(mt_merge_params);
+  size_t total = o_res + sizeof(mt_merge_result);
+  int rc = c->d_misc.reserve(total);
+  if (rc != MT_OK) return rc;
+  unsigned char *d = static_cast<unsigned char *>(c->d_misc.p);
+  hipStream_t st = c->stream;
+  const uint64_t off[2] = {0, n};
+  if (n) HIP_TRY(hipMemcpyAsync(d + o_pts, ts, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(d + o_off, off, sizeof off, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(d + o_mp, mp, sizeof *mp, hipMemcpyHostToDevice, st));
+
+  mtgpu::MergeLaunch L;
+  L.flags = nullptr;
+  L.pts = reinterpret_cast<const double *>(d + o_pts);
+  L.stream_off = reinterpret_cast<const unsigned long long *>(d + o_off);
+  L.n_frames_total = n;
+  L.mp = reinterpret_cast<const mt_merge_params *>(d + o_mp);
+  L.job_semantics = job_semantics;
+  L.ts_ws = reinterpret_cast<double *>(d + o_ws);
+  L.seg = reinterpret_cast<mt_segment *>(d + o_seg);
+  L.seg_cap = segs;
+  L.res = reinterpret_cast<mt_merge_result *>(d + o_res);
+  L.n_streams = 1;
+  L.stream = st;
+  hipError_t e = mtgpu::launch_merge(L);
+  if (e != hipSuccess) return hip_fail(e, "merge launch");
+  HIP_TRY(hipMemcpyAsync(res, d + o_res, sizeof *res, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  if (res->status != MT_OK) return fail(res->status, "timestamps contain NaN");
+  const uint64_t ncopy = res->n_segments < cap ? res->n_segments : cap;
+  if (ncopy) {
+    HIP_TRY(hipMemcpyAsync(out, d + o_seg, sizeof(mt_segment) * (size_t)ncopy, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+  }
+  if (res->n_segments > cap) return fail(MT_ERR_CAPACITY, "need %llu segments, capacity %llu",
+                                         (unsigned long long)res->n_segments, (unsigned long long)cap);
+  return MT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,41 @@
+// scan_kernels.h — launch interface between the C ABI (mtgpu_api.hip) and the
+// gfx950 scan kernels (scan_kernels.hip).  Internal; not part of the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mtgpu {
+
+// Kernel-side parameter block, derived on the host from mt_scan_params
+// (reference cfg: include/motion_trim/motion_scanner.hpp:86-93).
+struct ScanK {
+  unsigned long long thr;  // keep an MV iff |d|^2 >= thr   (src/motion_scanner.cpp:251)
+  int shift;               // block_shift                     (:255-256)
+  int gw, gh;              // grid_w, grid_h
+  int y_lo, y_hi;          // analysed rows [vertical_margin, gh - vertical_margin)  (:237-238)
+  unsigned int vec_need;   // vectors_needed                  (:272)
+  unsigned int clust_need; // max(1, clusters_needed)         (:288)
+  int W;                   // 64-bit words per activity-mask row = ceil(gw / 64)
+  int bands;               // row bands per frame
+  int band_rows;           // analysed rows per band
+  int cnt_words;           // LDS counter words per workgroup ((band_rows + 2) * gw, padded to 4)
+  int mask_rows;           // band_rows + 2
+};
+
+struct ScanLaunch {
+  const unsigned char *mv;
+  unsigned long long n_records;
+  const unsigned long long *frame_off;
+  const unsigned char *has_sd;
+  unsigned int n_frames;
+  unsigned char *flags;
+  unsigned int *frame_centres;  // n_frames words, only when k.bands > 1
+  ScanK k;
+  int block;
+  int lds_bytes;
+  hipStream_t stream;
+};
+
+hipError_t launch_scan(const ScanLaunch &L);
+
+}  // namespace mtgpu

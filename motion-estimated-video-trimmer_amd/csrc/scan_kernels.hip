@@ -1,0 +1,224 @@
+// scan_kernels.hip — gfx950 kernels for MotionScanner::check_frame
+// (reference: src/motion_scanner.cpp:217-295).  Integer threshold / scatter /
+// stencil work: HBM-read bound, no MFMA.
+//
+// Work item = (frame, row band).  One workgroup per item:
+//   phase 0  zero the band's vote counters in LDS           (:229 memset)
+//   phase 1  stream the frame's packed 40-byte records, one record per lane and
+//            load (bytes 4..15 of each record = w,h,src_x,src_y,dst_x,dst_y),
+//            threshold on |d|^2, map dst to a cell, LDS atomic vote (:242-268)
+//   phase 2a one wave per (row, 64-cell word): `count >= vectors_needed`
+//            -> __ballot -> 64-bit row masks in LDS           (:282)
+//   phase 2b one lane per (row, word): shifted-mask 4-neighbour test,
+//            __popcll, LDS reduction, compare with clusters_needed (:277-293)
+//
+// The u8 saturation at 255 of the reference (:265-266) is unobservable (only
+// `>= vectors_needed`, vectors_needed <= 255, is ever tested), so the 32-bit LDS
+// counters are bit-exact.  The early `return true` (:288-289) does not change the
+// value: result = (#centre cells >= max(1, clusters_needed)).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "scan_kernels.h"
+
+namespace mtgpu {
+
+typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
+typedef u32x3 u32x3_a4 __attribute__((aligned(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// Bytes 4..15 of a record: d.x = w | h<<8 | src_x<<16, d.y = src_y | dst_x<<16,
+// d.z = dst_y | pad<<16   (layout: include/mt_types.h, mt_mv).
+__device__ __forceinline__ u32x3 load_fields(const unsigned char *rec) {
+  return __builtin_nontemporal_load(reinterpret_cast<const u32x3_a4 *>(rec + 4));
+}
+
+// Threshold + cell mapping + vote for one record (src/motion_scanner.cpp:246-267).
+__device__ __forceinline__ void vote(const u32x3 d, const ScanK &k, int t0, int t1,
+                                     unsigned int *cnt) {
+  const int src_x = (int)d.x >> 16;
+  const int src_y = (int)(short)(d.y & 0xffffu);
+  const int dst_x = (int)d.y >> 16;
+  const int dst_y = (int)(short)(d.z & 0xffffu);
+  const unsigned int dx = (unsigned int)(dst_x - src_x);   // |dx| <= 65535
+  const unsigned int dy = (unsigned int)(dst_y - src_y);
+  // dx*dx < 2^32 exactly; the sum needs 34 bits.
+  const unsigned long long mag =
+      (unsigned long long)(dx * dx) + (unsigned long long)(dy * dy);
+  const int gx = dst_x >> k.shift;
+  const int gy = dst_y >> k.shift;
+  const bool in = (mag >= k.thr) & (gx >= 0) & (gx < k.gw) & (gy >= k.y_lo) & (gy < k.y_hi) &
+                  (gy >= t0) & (gy < t1);
+  if (in) atomicAdd(&cnt[(gy - t0) * k.gw + gx], 1u);
+}
+
+template <int BLOCK, int UNROLL>
+__global__ __launch_bounds__(BLOCK) void scan_frames_kernel(
+    const unsigned char *__restrict__ mv, unsigned long long n_records,
+    const unsigned long long *__restrict__ frame_off, const unsigned char *__restrict__ has_sd,
+    unsigned int item0, ScanK k, unsigned char *__restrict__ flags,
+    unsigned int *__restrict__ frame_centres) {
+  extern __shared__ __attribute__((aligned(16))) unsigned int lds[];
+  const int tid = threadIdx.x;
+  const unsigned int item = item0 + blockIdx.x;
+  const unsigned int f = item / (unsigned int)k.bands;
+  const int band = (int)(item - f * (unsigned int)k.bands);
+
+  unsigned long long r0 = frame_off[f], r1 = frame_off[f + 1];
+  r1 = r1 < n_records ? r1 : n_records;
+  r0 = r0 < r1 ? r0 : r1;
+  const bool sd = has_sd ? (has_sd[f] != 0) : (r1 > r0);
+  if (!sd) {                                   // :219-221 — no side data: false
+    if (k.bands == 1 && tid == 0) flags[f] = 0;
+    return;                                    // (bands > 1: finalize kernel writes 0)
+  }
+
+  // Band geometry: centres [c0,c1), tracked counter rows [t0,t1).
+  const int c0 = k.y_lo + band * k.band_rows;
+  const int c1 = min(k.y_hi, c0 + k.band_rows);
+  const int t0 = max(c0 - 1, 0);
+  const int t1 = min(c1 + 1, k.gh);
+  const int trows = t1 - t0;                   // may be <= 0 for an empty analysed range
+  const int W = k.W;
+
+  unsigned int *cnt = lds;                                         // [trows][gw]
+  unsigned long long *mask =
+      reinterpret_cast<unsigned long long *>(lds + k.cnt_words);   // [trows+2][W]
+  unsigned int *total = reinterpret_cast<unsigned int *>(mask + (size_t)k.mask_rows * W);
+
+  // ---- phase 0: zero counters, mask halo rows, total
+  {
+    u32x4 *c4 = reinterpret_cast<u32x4 *>(cnt);
+    const int n4 = k.cnt_words >> 2;
+    for (int i = tid; i < n4; i += BLOCK) c4[i] = (u32x4){0u, 0u, 0u, 0u};
+    for (int i = tid; i < k.mask_rows * W; i += BLOCK) mask[i] = 0ull;
+    if (tid == 0) *total = 0u;
+  }
+  __syncthreads();
+
+  // ---- phase 1: stream the records
+  if (trows > 0 && k.vec_need != 0u) {         // vec_need == 0: every cell is active anyway
+    const unsigned char *base = mv + r0 * 40ull;
+    const unsigned long long n = r1 - r0;
+    unsigned long long i = tid;
+    // main body: UNROLL independent loads in flight per lane
+    for (; i + (unsigned long long)(UNROLL - 1) * BLOCK < n; i += (unsigned long long)UNROLL * BLOCK) {
+      u32x3 d[UNROLL];
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) d[u] = load_fields(base + (i + (unsigned long long)u * BLOCK) * 40ull);
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) vote(d[u], k, t0, t1, cnt);
+    }
+    for (; i < n; i += BLOCK) vote(load_fields(base + i * 40ull), k, t0, t1, cnt);
+  }
+  __syncthreads();
+
+  // ---- phase 2a: activity masks, one wave per (tracked row, word)
+  if (trows > 0) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int ntask = trows * W;
+    for (int t = wave; t < ntask; t += BLOCK / 64) {
+      const int row = t / W, w = t - row * W;
+      const int x = w * 64 + lane;
+      const bool on = (x < k.gw) && (cnt[row * k.gw + x] >= k.vec_need);
+      const unsigned long long m = __ballot(on);
+      // mask row j holds grid row c0-1+j; tracked local row `row` is grid row t0+row
+      if (lane == 0) mask[(size_t)(row + t0 - c0 + 1) * W + w] = m;
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 2b: centre cells with an active 4-neighbour
+  {
+    const int crows = c1 - c0;
+    const int ntask = crows > 0 ? crows * W : 0;
+    unsigned int local = 0;
+    for (int t = tid; t < ntask; t += BLOCK) {
+      const int r = t / W, w = t - r * W;      // centre row c0 + r  -> mask row r + 1
+      const unsigned long long *mr = mask + (size_t)(r + 1) * W;
+      const unsigned long long m = mr[w];
+      if (m == 0ull) continue;
+      const unsigned long long up = mr[w - W], dn = mr[w + W];
+      const unsigned long long lcarry = (w > 0) ? (mr[w - 1] >> 63) : 0ull;
+      const unsigned long long rcarry = (w + 1 < W) ? (mr[w + 1] << 63) : 0ull;
+      const unsigned long long nb = (m << 1) | lcarry | (m >> 1) | rcarry | up | dn;
+      // centres are x in [1, gw-2]  (:280)
+      const int lo = max(1 - w * 64, 0), hi = min(k.gw - 1 - w * 64, 64);   // bits [lo,hi)
+      unsigned long long valid = 0ull;
+      if (hi > lo) {
+        valid = (hi >= 64) ? ~0ull : ((1ull << hi) - 1ull);
+        valid &= ~((1ull << lo) - 1ull);
+      }
+      local += (unsigned int)__popcll(m & nb & valid);
+    }
+    if (local) atomicAdd(total, local);
+  }
+  __syncthreads();
+
+  if (tid == 0) {
+    const unsigned int c = *total;
+    if (k.bands == 1) flags[f] = (c >= k.clust_need) ? 1 : 0;
+    else if (c) atomicAdd(&frame_centres[f], c);
+  }
+}
+
+// bands > 1: combine the per-band centre counts (one thread per frame).
+__global__ void finalize_flags_kernel(const unsigned long long *__restrict__ frame_off,
+                                      unsigned long long n_records,
+                                      const unsigned char *__restrict__ has_sd,
+                                      const unsigned int *__restrict__ frame_centres,
+                                      unsigned int n_frames, unsigned int clust_need,
+                                      unsigned char *__restrict__ flags) {
+  const unsigned int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= n_frames) return;
+  unsigned long long r0 = frame_off[f], r1 = frame_off[f + 1];
+  r1 = r1 < n_records ? r1 : n_records;
+  r0 = r0 < r1 ? r0 : r1;
+  const bool sd = has_sd ? (has_sd[f] != 0) : (r1 > r0);
+  flags[f] = (sd && frame_centres[f] >= clust_need) ? 1 : 0;
+}
+
+// ------------------------------------------------------------------ launchers
+
+template <int BLOCK>
+static hipError_t launch_block(const ScanLaunch &L) {
+  auto kern = scan_frames_kernel<BLOCK, 4>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, L.lds_bytes);
+  if (e != hipSuccess) return e;
+  const unsigned long long items = (unsigned long long)L.n_frames * (unsigned long long)L.k.bands;
+  const unsigned long long chunk = 1ull << 30;
+  for (unsigned long long i0 = 0; i0 < items; i0 += chunk) {
+    const unsigned int n = (unsigned int)((items - i0 < chunk) ? (items - i0) : chunk);
+    hipLaunchKernelGGL(kern, dim3(n), dim3(BLOCK), L.lds_bytes, L.stream, L.mv, L.n_records,
+                       L.frame_off, L.has_sd, (unsigned int)i0, L.k, L.flags, L.frame_centres);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
+hipError_t launch_scan(const ScanLaunch &L) {
+  if (L.n_frames == 0) return hipSuccess;
+  hipError_t e;
+  if (L.k.bands > 1) {
+    e = hipMemsetAsync(L.frame_centres, 0, sizeof(unsigned int) * (size_t)L.n_frames, L.stream);
+    if (e != hipSuccess) return e;
+  }
+  switch (L.block) {
+    case 256: e = launch_block<256>(L); break;
+    case 512: e = launch_block<512>(L); break;
+    case 1024: e = launch_block<1024>(L); break;
+    default: return hipErrorInvalidValue;
+  }
+  if (e != hipSuccess) return e;
+  if (L.k.bands > 1) {
+    const unsigned int nb = (L.n_frames + 255u) / 256u;
+    hipLaunchKernelGGL(finalize_flags_kernel, dim3(nb), dim3(256), 0, L.stream, L.frame_off,
+                       L.n_records, L.has_sd, L.frame_centres, L.n_frames, L.k.clust_need, L.flags);
+    e = hipGetLastError();
+  }
+  return e;
+}
+
+}  // namespace mtgpu

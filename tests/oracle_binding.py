@@ -1,0 +1,148 @@
+"""ctypes binding of oracle/libmt_oracle.so — TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_LIB = os.path.join(ROOT, "oracle", "libmt_oracle.so")
+
+import mvtrim_amd as m  # noqa: E402  (record dtypes only)
+from mvtrim_amd._abi import MergeParamsC, MergeResultC, ScanParamsC  # noqa: E402
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(ORACLE_LIB)
+        L.mto_version.restype = C.c_char_p
+        L.mto_params_from_config.restype = C.c_int
+        L.mto_params_from_config.argtypes = [C.POINTER(ScanParamsC), C.c_int, C.c_int, C.c_double,
+                                             C.c_int, C.c_int, C.c_int, C.c_int, C.c_float]
+        L.mto_check_frame.restype = C.c_int
+        L.mto_check_frame.argtypes = [C.POINTER(ScanParamsC), C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+        L.mto_check_frame_count.restype = C.c_int
+        L.mto_check_frame_count.argtypes = [C.POINTER(ScanParamsC), C.c_void_p, C.c_int64, C.c_int,
+                                            C.c_void_p, C.POINTER(C.c_int64)]
+        L.mto_scan_frames.restype = C.c_int
+        L.mto_scan_frames.argtypes = [C.POINTER(ScanParamsC), C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_uint32, C.c_void_p]
+        L.mto_scan_frames_mt.restype = C.c_int
+        L.mto_scan_frames_mt.argtypes = L.mto_scan_frames.argtypes + [C.c_int]
+        L.mto_frame_skip.restype = C.c_int
+        L.mto_frame_skip.argtypes = [C.c_double, C.c_double]
+        L.mto_filter_frames.restype = C.c_int64
+        L.mto_filter_frames.argtypes = [C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_double,
+                                        C.c_int, C.c_void_p, C.c_void_p]
+        L.mto_chunks.restype = C.c_int64
+        L.mto_chunks.argtypes = [C.c_double, C.c_double, C.c_void_p, C.c_int64]
+        L.mto_sort_unique.restype = C.c_int64
+        L.mto_sort_unique.argtypes = [C.c_void_p, C.c_int64]
+        L.mto_merge_segments.restype = C.c_int
+        L.mto_merge_segments.argtypes = [C.c_void_p, C.c_int64, C.POINTER(MergeParamsC), C.c_int,
+                                         C.c_void_p, C.c_int64, C.POINTER(MergeResultC)]
+        L.mto_motion_scalar.restype = C.c_int
+        L.mto_motion_scalar.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int64]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def params_from_config(width, height, mv_threshold_sq=16.0, block_size=16, block_shift=4,
+                       vectors_needed=2, clusters_needed=2, vertical_mask=0.05):
+    c = ScanParamsC()
+    rc = lib().mto_params_from_config(C.byref(c), width, height, mv_threshold_sq, block_size,
+                                      block_shift, vectors_needed, clusters_needed, vertical_mask)
+    if rc:
+        raise ValueError(f"mto_params_from_config -> {rc}")
+    return m.ScanParams.from_c(c)
+
+
+def check_frame(params, mv, has_sd=True, count_centres=False):
+    c = params.to_c()
+    mv = np.ascontiguousarray(mv, dtype=m.MV_DTYPE)
+    grid = np.zeros(params.grid_w * params.grid_h, dtype=np.uint8)
+    if count_centres:
+        n = C.c_int64(0)
+        r = lib().mto_check_frame_count(C.byref(c), _p(mv), len(mv), 1 if has_sd else 0, _p(grid), C.byref(n))
+        assert r >= 0
+        return r, n.value, grid.reshape(params.grid_h, params.grid_w)
+    r = lib().mto_check_frame(C.byref(c), _p(mv), len(mv), 1 if has_sd else 0, _p(grid))
+    assert r >= 0
+    return r
+
+
+def scan_frames(params, mv, frame_off, has_sd=None, nthreads=1):
+    c = params.to_c()
+    mv = np.ascontiguousarray(mv, dtype=m.MV_DTYPE)
+    off = np.ascontiguousarray(frame_off, dtype=np.uint64)
+    sd = None if has_sd is None else np.ascontiguousarray(has_sd, dtype=np.uint8)
+    n = len(off) - 1
+    flags = np.zeros(n, dtype=np.uint8)
+    if nthreads > 1:
+        rc = lib().mto_scan_frames_mt(C.byref(c), _p(mv), _p(off), _p(sd), n, _p(flags), nthreads)
+    else:
+        rc = lib().mto_scan_frames(C.byref(c), _p(mv), _p(off), _p(sd), n, _p(flags))
+    if rc:
+        raise ValueError(f"mto_scan_frames -> {rc}")
+    return flags
+
+
+def filter_frames(frame_pts, time_base, start, end, skip):
+    pts = np.ascontiguousarray(frame_pts, dtype=np.int64)
+    an = np.zeros(len(pts), dtype=np.uint8)
+    sec = np.zeros(len(pts), dtype=np.float64)
+    used = lib().mto_filter_frames(_p(pts), len(pts), time_base, start, end, skip, _p(an), _p(sec))
+    idx = [i for i in range(int(used)) if an[i]]
+    return idx, [float(sec[i]) for i in idx]
+
+
+def chunks(duration, chunk_sec):
+    n = lib().mto_chunks(duration, chunk_sec, None, 0)
+    out = np.zeros(n, dtype=m.SEGMENT_DTYPE)
+    lib().mto_chunks(duration, chunk_sec, _p(out), n)
+    return [(float(a), float(b), i) for i, (a, b) in enumerate(out)]
+
+
+def sort_unique(ts):
+    a = np.array(ts, dtype=np.float64)
+    n = lib().mto_sort_unique(_p(a), len(a))
+    if n < 0:
+        raise ValueError("NaN timestamp")
+    return a[:n].copy()
+
+
+def merge_segments(ts_sorted_unique, mp, job_semantics=False):
+    ts = np.ascontiguousarray(ts_sorted_unique, dtype=np.float64)
+    seg = np.zeros(len(ts) + 1, dtype=m.SEGMENT_DTYPE)
+    res = MergeResultC()
+    c_mp = mp.to_c()
+    rc = lib().mto_merge_segments(_p(ts) if len(ts) else None, len(ts), C.byref(c_mp),
+                                  1 if job_semantics else 0, _p(seg), len(seg), C.byref(res))
+    if rc:
+        raise ValueError(f"mto_merge_segments -> {rc}")
+    out = {n: getattr(res, n) for n, _ in MergeResultC._fields_}
+    return seg[:res.n_segments].copy(), out
+
+
+def pool_and_merge(ts_any_order, mp, job_semantics=False):
+    """sort + unique + merge, i.e. pipeline.cpp:302-358 on the pooled timestamps."""
+    return merge_segments(sort_unique(ts_any_order), mp, job_semantics)
+
+
+def motion_scalar(mv, frame_off, pts_sec, n_sec):
+    mv = np.ascontiguousarray(mv, dtype=m.MV_DTYPE)
+    off = np.ascontiguousarray(frame_off, dtype=np.uint64)
+    pts = np.ascontiguousarray(pts_sec, dtype=np.float64)
+    acc = np.zeros(n_sec, dtype=np.float64)
+    rc = lib().mto_motion_scalar(_p(mv), _p(off), _p(pts), len(off) - 1, _p(acc), n_sec)
+    assert rc == 0
+    return acc

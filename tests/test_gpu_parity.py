@@ -1,0 +1,357 @@
+"""GPU parity tests (run with `-m gpu` on the MI355X box): the HIP path, called
+through the C ABI (libmtgpu.so), against the CPU oracle on identical inputs.
+
+Bar: bit-exact.  Per-frame flags are integers; segment doubles are compared by
+their 64-bit patterns.
+"""
+import numpy as np
+import pytest
+
+import mvtrim_amd as m
+from mvtrim_amd import synth
+
+import oracle_binding as ob
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def junk_padding(mv, rng):
+    """Fill the padding bytes of the records (14-15, 34-39) with junk: the scan must ignore them."""
+    raw = mv.view(np.uint8).reshape(-1, 40)
+    if len(raw):
+        raw[:, 14:16] = rng.randint(0, 256, size=(len(raw), 2))
+        raw[:, 34:40] = rng.randint(0, 256, size=(len(raw), 6))
+    return mv
+
+
+def assert_scan_parity(scanner, params, mv, off, has_sd):
+    want = ob.scan_frames(params, mv, off, has_sd)
+    got = scanner.check_frames(m.FrameBatch(mv, off, None, has_sd))
+    bad = np.flatnonzero(want != got)
+    assert bad.size == 0, f"{bad.size} frames differ, first {bad[:8]}: want {want[bad[:8]]} got {got[bad[:8]]}"
+    return want
+
+
+# ------------------------------------------------------------------ scan: streams
+
+@pytest.mark.parametrize("cfg", ["code_defaults", "shipped_env"])
+@pytest.mark.parametrize("sub", [1, 2])
+def test_scan_1080p_stream(gpu_scanner_factory, cfg, sub):
+    kw = m.config.CODE_DEFAULTS if cfg == "code_defaults" else m.config.SHIPPED_ENV
+    spec = synth.spec_1080p(seed=11 + sub, sub=sub)
+    spec.events = synth.scripted_events(spec, 120)
+    mv, off, pts, sd = synth.gen_stream(spec, 120)
+    p = ob.params_from_config(1920, 1080, **kw)
+    assert (p.grid_w, p.grid_h, p.vertical_margin) == (120, 68, 3)
+    s = gpu_scanner_factory(m.ScanParams.from_config(1920, 1080, **kw))
+    assert s.params == p
+    want = assert_scan_parity(s, p, mv, off, sd)
+    assert 0 < want.sum() < len(want)          # the stream has both motion and still frames
+    # has_sd == NULL convention: side data iff >= 1 record (identical here)
+    got2 = s.check_frames(m.FrameBatch(mv, off))
+    assert np.array_equal(got2, want)
+
+
+def test_scan_4k_stream(gpu_scanner_factory):
+    spec = synth.spec_4k(seed=5)
+    spec.events = synth.scripted_events(spec, 16)
+    spec.events.append(synth.Event(3, 9, 100, 60, 4, 3, 9, -5))
+    mv, off, pts, sd = synth.gen_stream(spec, 16)
+    p = ob.params_from_config(3840, 2160)
+    assert (p.grid_w, p.grid_h, p.vertical_margin) == (240, 135, 6)
+    s = gpu_scanner_factory(p)
+    want = assert_scan_parity(s, p, mv, off, sd)
+    assert want.sum() >= 6
+
+
+def test_scan_4k_fine_grid_multiband(gpu_scanner_factory):
+    """960x540 grid (BLOCK_SIZE=4, SHIFT=2): the vote grid exceeds LDS -> row bands."""
+    spec = synth.spec_4k_fine(seed=9)
+    spec.events = [synth.Event(1, 3, 300, 200, 6, 6, 9, 3),      # inside one band
+                   synth.Event(2, 4, 500, 27, 5, 1, -7, 0)]      # single row at y_min
+    mv, off, pts, sd = synth.gen_stream(spec, 5)
+    kw = dict(block_size=4, block_shift=2)
+    p = ob.params_from_config(3840, 2160, **kw)
+    assert (p.grid_w, p.grid_h, p.vertical_margin) == (960, 540, 27)
+    s = gpu_scanner_factory(p)
+    assert s.plan["bands"] > 1
+    assert_scan_parity(s, p, mv, off, sd)
+
+
+def test_fine_grid_cluster_across_band_seam(gpu_scanner_factory):
+    """Two active cells stacked vertically exactly on a band seam: each band must see the
+    other's row as a neighbour (halo rows)."""
+    p = ob.params_from_config(3840, 2160, block_size=4, block_shift=2, vectors_needed=1, clusters_needed=2)
+    s = gpu_scanner_factory(p)
+    band_rows = s.plan["band_rows"]
+    seam = p.vertical_margin + band_rows          # first centre row of band 1
+    frames = []
+    for (ya, yb) in [(seam - 1, seam), (seam, seam + 1), (seam - 2, seam - 1), (seam - 1, seam + 1)]:
+        mv = np.zeros(2, dtype=m.MV_DTYPE)
+        mv["dst_x"] = 400 * 4 + 2
+        mv["dst_y"] = [ya * 4 + 2, yb * 4 + 2]
+        mv["src_x"] = mv["dst_x"] - 9
+        mv["src_y"] = mv["dst_y"]
+        frames.append(mv)
+    b = m.FrameBatch.from_frames(frames)
+    want = assert_scan_parity(s, p, b.mv, b.frame_off, b.has_sd)
+    assert list(want) == [1, 1, 1, 0]
+
+
+# ------------------------------------------------------------------ scan: edge cases
+
+EDGE_CFGS = [
+    # (width, height, kwargs)
+    (1920, 1080, dict()),
+    (1920, 1080, dict(vertical_mask=0.0)),                              # margin 0: grid edges are centres
+    (1920, 1080, dict(vectors_needed=1, clusters_needed=1)),
+    (1920, 1080, dict(vectors_needed=0)),                               # every cell active
+    (1920, 1080, dict(vectors_needed=255)),
+    (1920, 1080, dict(vectors_needed=256 + 3)),                         # uint8 wrap -> 3
+    (1920, 1080, dict(clusters_needed=0)), (1920, 1080, dict(clusters_needed=-5)),
+    (1920, 1080, dict(clusters_needed=100000)),
+    (1920, 1080, dict(mv_threshold_sq=0.0)), (1920, 1080, dict(mv_threshold_sq=-1.0)),
+    (1920, 1080, dict(mv_threshold_sq=float("nan"))), (1920, 1080, dict(mv_threshold_sq=float("inf"))),
+    (1920, 1080, dict(mv_threshold_sq=24.5)), (1920, 1080, dict(mv_threshold_sq=25.0)),
+    (1920, 1080, dict(mv_threshold_sq=2.0e9)),
+    (1920, 1080, dict(vertical_mask=0.5)), (1920, 1080, dict(vertical_mask=0.6)),   # empty analysed range
+    (16, 16, dict(vertical_mask=0.0)), (32, 48, dict(vertical_mask=0.0)), (48, 48, dict(vertical_mask=0.0)),
+    (1008, 64, dict(vertical_mask=0.0)), (1024, 64, dict(vertical_mask=0.0)),       # gw 63, 64
+    (1040, 64, dict(vertical_mask=0.0)), (2064, 96, dict()),                         # gw 65, 129
+    (1920, 1080, dict(block_size=8, block_shift=3)),                                 # 240x135 on 1080p
+    (1920, 1080, dict(block_size=16, block_shift=5)),                                # size/shift mismatch
+    (640, 480, dict(block_size=1, block_shift=0, vectors_needed=1)),                 # 640x480 cells
+]
+
+
+@pytest.mark.parametrize("width,height,kw", EDGE_CFGS)
+def test_scan_edge_configs(gpu_scanner_factory, width, height, kw):
+    import zlib
+    rng = np.random.RandomState(zlib.crc32(repr((width, height, sorted(kw.items()))).encode()) % (2 ** 31))
+    p = ob.params_from_config(width, height, **kw)
+    assert m.ScanParams.from_config(width, height, **kw) == p or np.isnan(p.mv_threshold_sq)
+    s = gpu_scanner_factory(p)
+    mv, off, sd = synth.random_frames(rng, 48, 3000, width, height)
+    junk_padding(mv, rng)
+    want = assert_scan_parity(s, p, mv, off, sd)
+    # and with the NULL has_sd convention
+    got = s.check_frames(m.FrameBatch(mv, off))
+    assert np.array_equal(got, ob.scan_frames(p, mv, off, None))
+    del want
+
+
+def test_scan_counter_saturation(gpu_scanner_factory):
+    """> 255 votes in one cell (the reference's u8 saturates at 255, :265-266) and
+    vectors_needed = 255: active iff >= 255 votes."""
+    p = ob.params_from_config(1920, 1080, vectors_needed=255, clusters_needed=1)
+    s = gpu_scanner_factory(p)
+    frames = []
+    for na, nb in [(254, 300), (255, 255), (1000, 70000), (255, 254)]:
+        mv = np.zeros(na + nb, dtype=m.MV_DTYPE)
+        mv["dst_x"][:na], mv["dst_x"][na:] = 800, 816
+        mv["dst_y"] = 480
+        mv["src_x"] = mv["dst_x"] + 10
+        mv["src_y"] = mv["dst_y"]
+        frames.append(mv)
+    b = m.FrameBatch.from_frames(frames)
+    want = assert_scan_parity(s, p, b.mv, b.frame_off, b.has_sd)
+    assert list(want) == [0, 1, 1, 0]
+
+
+def test_scan_empty_and_sideless_frames(gpu_scanner_factory):
+    p0 = ob.params_from_config(1920, 1080, vectors_needed=0, clusters_needed=1)
+    s0 = gpu_scanner_factory(p0)
+    one = np.zeros(1, dtype=m.MV_DTYPE)
+    b = m.FrameBatch.from_frames([None, np.zeros(0, dtype=m.MV_DTYPE), one, None])
+    # vectors_needed == 0: "side data with zero records" -> phase 2 on an all-active grid -> true,
+    # "no side data" -> false (reference :219-221 vs :282)
+    want = assert_scan_parity(s0, p0, b.mv, b.frame_off, b.has_sd)
+    assert list(want) == [0, 1, 1, 0]
+    assert s0.check_frames(m.FrameBatch(b.mv, np.zeros(1, dtype=np.uint64))).size == 0
+
+
+def test_scan_device_resident_matches_host_path(gpu_scanner_factory):
+    import torch
+    spec = synth.spec_1080p(seed=3, sub=1)
+    spec.events = synth.scripted_events(spec, 64)
+    mv, off, pts, sd = synth.gen_stream(spec, 64)
+    p = ob.params_from_config(1920, 1080)
+    s = gpu_scanner_factory(p)
+    want = ob.scan_frames(p, mv, off, sd)
+    d_mv = torch.from_numpy(mv.view(np.uint8).copy()).cuda()
+    d_off = torch.from_numpy(off.astype(np.int64)).cuda()
+    d_sd = torch.from_numpy(sd).cuda()
+    got = s.check_frames_device(d_mv, d_off, d_sd)
+    torch.cuda.synchronize()
+    assert np.array_equal(got.cpu().numpy(), want)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        got2 = s.check_frames_device(d_mv, d_off, None)
+    side.synchronize()
+    assert np.array_equal(got2.cpu().numpy(), want)
+
+
+def test_scan_batch_properties_full_size(gpu_scanner_factory):
+    """Size-independent properties at bench scale (the oracle is too slow to recheck all of
+    it): the flags of a tiled batch are the tile's flags repeated, and permuting frames
+    permutes flags."""
+    import torch
+    spec = synth.spec_1080p(seed=21)
+    spec.events = synth.scripted_events(spec, 32)
+    mv, off, pts, sd = synth.gen_stream(spec, 32)
+    p = ob.params_from_config(1920, 1080)
+    s = gpu_scanner_factory(p)
+    want = ob.scan_frames(p, mv, off, None)
+    reps = 32                                   # 1024 frames, ~1.3 GB of records
+    d_tile = torch.from_numpy(mv.view(np.uint8).copy()).cuda()
+    d_mv = d_tile.repeat(reps)
+    counts = np.diff(off.astype(np.int64))
+    off_big = np.concatenate([[0], np.cumsum(np.tile(counts, reps))]).astype(np.int64)
+    got = s.check_frames_device(d_mv, torch.from_numpy(off_big).cuda()).cpu().numpy()
+    assert np.array_equal(got, np.tile(want, reps))
+    # reversed frame order over the same record array: offsets select frames back to front
+    starts = off_big[:-1][::-1].copy()
+    # a reversed batch needs its own packed array; build it on the host for the tile only
+    order = np.arange(32)[::-1]
+    frames = [mv[int(off[i]):int(off[i + 1])] for i in order]
+    b = m.FrameBatch.from_frames(frames)
+    assert np.array_equal(s.check_frames(m.FrameBatch(b.mv, b.frame_off)), want[order])
+    del starts
+
+
+# ------------------------------------------------------------------ merge
+
+def merge_case(scanner, ts, mp, job):
+    want_seg, want_res = ob.pool_and_merge(ts, mp, job)
+    got_seg, got_res = scanner.merge_segments(ts, mp, job)
+    assert got_res["n_timestamps"] == want_res["n_timestamps"]
+    assert got_res["n_segments"] == want_res["n_segments"]
+    assert got_res["do_cut"] == want_res["do_cut"]
+    assert bits([got_res["time_removed"], got_res["saved_pct"]]).tolist() == \
+        bits([want_res["time_removed"], want_res["saved_pct"]]).tolist()
+    assert np.array_equal(bits(got_seg["start"]), bits(want_seg["start"]))
+    assert np.array_equal(bits(got_seg["end"]), bits(want_seg["end"]))
+    return want_seg, want_res
+
+
+@pytest.mark.parametrize("job", [False, True])
+def test_merge_random(gpu_scanner_factory, job):
+    s = gpu_scanner_factory(ob.params_from_config(1920, 1080))
+    rng = np.random.RandomState(5)
+    for n in [0, 1, 2, 3, 17, 64, 65, 1023, 1024, 1025, 5000, 40000]:
+        dur = 600.0
+        base = np.sort(rng.rand(n) * dur)
+        # cluster the timestamps so gaps fall on both sides of MAX_GAP_SEC
+        ts = np.round(base / 7.0) * 7.0 + rng.rand(n) * 3.0 if n else base
+        for variant in ("sorted", "shuffled", "dups"):
+            v = np.sort(ts)
+            if variant == "shuffled":
+                v = rng.permutation(v)
+            if variant == "dups" and n:
+                v = rng.permutation(np.concatenate([v, v[: n // 2 + 1], v[:1]]))
+            for mp in (m.MergeParams(duration=dur, max_gap_sec=5.0, padding_sec=0.5, min_savings_pct=5.0),
+                       m.MergeParams(duration=dur * 0.5, max_gap_sec=0.25, padding_sec=2.0, min_savings_pct=5.0),
+                       m.MergeParams(duration=0.0, max_gap_sec=1.0, padding_sec=0.0, min_savings_pct=5.0)):
+                merge_case(s, v, mp, job)
+
+
+def test_merge_frame_timestamps_and_capacity(gpu_scanner_factory):
+    s = gpu_scanner_factory(ob.params_from_config(1920, 1080))
+    spec = synth.spec_1080p()
+    idx = np.r_[301:720, 1801:1830, 4000:4002]
+    ts = np.array([spec.pts_seconds(i) for i in idx])
+    mp = m.MergeParams(duration=150.0, max_gap_sec=5.0, padding_sec=0.5, min_savings_pct=5.0)
+    seg, res = merge_case(s, ts, mp, True)
+    assert res["n_segments"] == 3 and res["do_cut"] == 1
+    # capacity: fewer slots than segments -> MT_ERR_CAPACITY, n_segments still reported
+    with pytest.raises(m.MtgpuError) as ei:
+        s.merge_segments(ts, mp, False, cap=2)
+    assert ei.value.code == 2
+    with pytest.raises(m.MtgpuError) as ei:
+        s.merge_segments(np.array([1.0, float("nan")]), mp)
+    assert ei.value.code == 1
+
+
+def test_merge_streams_on_device(gpu_scanner_factory):
+    import torch
+    p = ob.params_from_config(1920, 1080)
+    s = gpu_scanner_factory(p)
+    rng = np.random.RandomState(8)
+    n_streams = 9
+    lens = [0, 1, 700, 2048, 33, 5000, 1024, 1, 300]
+    flags, pts, mps, off = [], [], [], [0]
+    for i, n in enumerate(lens):
+        f = (rng.rand(n) < 0.3).astype(np.uint8)
+        # bursts
+        for _ in range(3):
+            if n > 10:
+                a = rng.randint(0, n - 5)
+                f[a:a + rng.randint(1, 60)] = 1
+        if i == 7:
+            f[:] = 0
+        t = np.arange(n) * (1.0 / 30.0) + i
+        if i == 4:
+            t = rng.permutation(t)                    # out-of-order stream (pooled chunks)
+        if i == 8:
+            t = np.repeat(t[::3], 3)[:n]              # duplicates
+        flags.append(f)
+        pts.append(t)
+        off.append(off[-1] + n)
+        mps.append(m.MergeParams(duration=float(n) / 30.0 + i, max_gap_sec=1.0 + 0.5 * i,
+                                 padding_sec=0.25 * i, min_savings_pct=5.0))
+    flags = np.concatenate(flags)
+    pts = np.concatenate(pts)
+    mp_rec = np.concatenate([x.to_record() for x in mps])
+    for job in (False, True):
+        seg, res = s.merge_streams_device(
+            torch.from_numpy(flags).cuda(), torch.from_numpy(pts).cuda(),
+            torch.from_numpy(np.array(off, dtype=np.int64)).cuda(),
+            torch.from_numpy(mp_rec.view(np.uint8).copy()).cuda(), job_semantics=job, seg_cap=4096)
+        torch.cuda.synchronize()
+        seg = seg.cpu().numpy()
+        res = m.results_from_bytes(res.cpu().numpy())
+        for i in range(n_streams):
+            a, b = off[i], off[i + 1]
+            want_seg, want_res = ob.pool_and_merge(pts[a:b][flags[a:b] != 0], mps[i], job)
+            assert res[i]["status"] == 0
+            assert res[i]["n_timestamps"] == want_res["n_timestamps"], i
+            assert res[i]["n_segments"] == want_res["n_segments"], i
+            assert res[i]["do_cut"] == want_res["do_cut"], i
+            k = int(res[i]["n_segments"])
+            assert np.array_equal(bits(seg[i, :k, 0]), bits(want_seg["start"])), i
+            assert np.array_equal(bits(seg[i, :k, 1]), bits(want_seg["end"])), i
+            assert bits([res[i]["time_removed"], res[i]["saved_pct"]]).tolist() == \
+                bits([want_res["time_removed"], want_res["saved_pct"]]).tolist()
+
+
+def test_end_to_end_stream_segments(gpu_scanner_factory):
+    """Synthetic 1080p stream -> flags -> timestamps -> segments, GPU vs oracle, through
+    the reference-shaped host interface (scan_range per chunk, pooled, merged)."""
+    spec = synth.spec_1080p(seed=33, sub=1)
+    n = 600                                           # 20 s at 30 fps
+    spec.events = synth.scripted_events(spec, n)
+    frames = [synth.gen_frame(spec, i) for i in range(n)]
+    ticks = [spec.pts_ticks(i) for i in range(n)]
+    tb = 1.0 / spec.tb_den
+    duration = n / spec.fps
+    p = ob.params_from_config(1920, 1080)
+    s = gpu_scanner_factory(p)
+    pooled_gpu, pooled_cpu = [], []
+    for (c0, c1, _) in m.make_chunks(duration, 6.0):
+        # a decoder seeks back to the previous keyframe: hand over frames from one GOP earlier
+        first = max(0, int(c0 * spec.fps) - spec.gop)
+        sub_ticks, sub_frames = ticks[first:], frames[first:]
+        pooled_gpu.append(s.scan_range(sub_ticks, sub_frames, tb, c0, c1, spec.fps, target_fps=10.0))
+        idx, pts = ob.filter_frames(sub_ticks, tb, c0, c1, m.frame_skip(spec.fps, 10.0))
+        b = m.FrameBatch.from_frames([sub_frames[i] for i in idx])
+        fl = ob.scan_frames(p, b.mv, b.frame_off, b.has_sd)
+        pooled_cpu.append([t for t, f in zip(pts, fl) if f])
+    assert pooled_gpu == pooled_cpu
+    ts = [t for c in reversed(pooled_gpu) for t in c]  # workers finish in any order
+    assert len(ts) > 10
+    mp = m.MergeParams(duration=duration)
+    merge_case(s, np.array(ts), mp, True)
