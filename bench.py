@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""MV-scan bench (BASELINE.json metric: "MV-scan frames/sec at 1080p grid").
+
+A step = one pass of the hot path over one device-resident batch of synthetic
+1080p AVMotionVector arrays (config "Synthetic 1080p MV arrays, 120x68 16px grid,
+30 fps stream", dense8x8 = 32 640 records = 1 305 600 B per P-frame):
+    scan kernel (flags per frame)  ->  stream merge kernel (segments per stream)
+    [N > 1: one RCCL all_gather of the per-GPU segment lists]
+Inputs are resident in HBM before the timed region.  Frames shard across ranks
+(weak scaling: every rank owns `--frames` frames of its own streams).
+
+Prints ONE JSON line on rank 0 (contract in the task statement), including
+  roofline     — the scan kernel: algorithmic bytes / live HIP-event duration vs 8 TB/s
+  cpu_baseline — the C oracle timed on this host's cores on a bounded sample (N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--frames", type=int, default=4096, help="frames per GPU per step")
+    ap.add_argument("--streams", type=int, default=8, help="streams per GPU (frames split evenly)")
+    ap.add_argument("--distinct", type=int, default=60, help="distinct generated frames per GPU (tiled)")
+    ap.add_argument("--workload", default="1080p_dense8x8",
+                    choices=["1080p_dense8x8", "1080p_dense16", "4k_dense8x8", "4k_fine"])
+    ap.add_argument("--params", default="code_defaults", choices=["code_defaults", "shipped_env"])
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample budget (0 = skip)")
+    ap.add_argument("--no-merge", action="store_true", help="time the scan kernel alone")
+    return ap.parse_args()
+
+
+def make_spec(workload, seed):
+    from mvtrim_amd import synth
+    if workload == "1080p_dense8x8":
+        return synth.spec_1080p(seed=seed, sub=2), (1920, 1080, {})
+    if workload == "1080p_dense16":
+        return synth.spec_1080p(seed=seed, sub=1), (1920, 1080, {})
+    if workload == "4k_dense8x8":
+        return synth.spec_4k(seed=seed, sub=2), (3840, 2160, {})
+    return synth.spec_4k_fine(seed=seed), (3840, 2160, dict(block_size=4, block_shift=2))
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import torch.distributed as dist
+    import mvtrim_amd as m
+    from mvtrim_amd import synth
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    # ---------------- synthetic input: `distinct` generated frames, tiled to `frames`
+    spec, (W, H, gridkw) = make_spec(a.workload, seed=1000 + rank)
+    spec.events = synth.scripted_events(spec, a.distinct)
+    mv, off, pts, sd = synth.gen_stream(spec, a.distinct)
+    kw = dict(m.config.CODE_DEFAULTS if a.params == "code_defaults" else m.config.SHIPPED_ENV)
+    kw.update(gridkw)
+    if spec.sub == 1 and a.workload != "4k_fine":
+        kw["vectors_needed"] = 1      # one record per cell can never collect 2 votes in a cell
+    params = m.ScanParams.from_config(W, H, **kw)
+    scanner = m.MotionScanner(params, device=local)
+
+    reps = (a.frames + a.distinct - 1) // a.distinct
+    counts = np.tile(np.diff(off.astype(np.int64)), reps)[: a.frames]
+    off_big = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    d_tile = torch.from_numpy(mv.view(np.uint8).copy()).to(dev)
+    d_mv = d_tile.repeat(reps)[: int(off_big[-1]) * 40].contiguous()
+    del d_tile
+    d_off = torch.from_numpy(off_big).to(dev)
+    d_flags = torch.empty(a.frames, dtype=torch.uint8, device=dev)
+    n_records = int(off_big[-1])
+    alg_bytes = 40 * n_records + 9 * a.frames          # 40*N_mv + 8 (offset) + 1 (flag) per frame
+
+    # streams: frames split evenly; pts restart per stream at 30 fps
+    S = max(1, min(a.streams, a.frames))
+    per = a.frames // S
+    stream_off = np.array([i * per for i in range(S)] + [a.frames], dtype=np.int64)
+    pts_big = np.concatenate([np.array([spec.pts_seconds(i) for i in range(stream_off[s + 1] - stream_off[s])])
+                              for s in range(S)])
+    mp = np.concatenate([m.MergeParams(duration=float(stream_off[s + 1] - stream_off[s]) / spec.fps).to_record()
+                         for s in range(S)])
+    d_pts = torch.from_numpy(pts_big).to(dev)
+    d_soff = torch.from_numpy(stream_off).to(dev)
+    d_mp = torch.from_numpy(mp.view(np.uint8).copy()).to(dev)
+    SEG_CAP = 64
+
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps)]
+    gathered = None
+
+    def step(i=None):
+        nonlocal gathered
+        if i is not None:
+            ev0[i].record()
+        scanner.check_frames_device(d_mv, d_off, None, d_flags)
+        if i is not None:
+            ev1[i].record()
+        if a.no_merge:
+            return None
+        seg, res = scanner.merge_streams_device(d_flags, d_pts, d_soff, d_mp, True, SEG_CAP)
+        if world > 1:
+            # the only exchange step of the path: per-GPU segment lists to every rank (RCCL over xGMI)
+            packed = torch.cat([seg.reshape(S, -1).view(torch.uint8), res], dim=1)
+            if gathered is None:
+                gathered = torch.empty((world,) + tuple(packed.shape), dtype=torch.uint8, device=dev)
+            dist.all_gather_into_tensor(gathered, packed)
+        return seg, res
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = None
+    for i in range(a.steps):
+        out = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in zip(ev0, ev1)]))
+    flags_host = d_flags.cpu().numpy()
+
+    if rank == 0:
+        total_frames = a.frames * world * a.steps
+        value = total_frames / dt
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # HBM bytes/launch from a --pmc run, if committed
+        if os.path.exists(tp):
+            try:
+                rec = json.load(open(tp)).get(f"{a.workload}:{a.frames}")
+                traffic = rec["hbm_bytes_per_launch"] if rec else None
+            except Exception:
+                traffic = None
+        cpu = None
+        if world == 1 and a.cpu_seconds > 0:
+            cpu = cpu_baseline(params, mv, off, flags_host[: a.distinct], a.cpu_seconds, a.workload)
+        line = {
+            "metric": "MV-scan frames/sec at 1080p grid" if a.workload.startswith("1080p") else "MV-scan frames/sec",
+            "value": value, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "int16/u32 (integer threshold + vote), f64 (segment merge)",
+            "data": "synthetic",
+            "config": {"workload": f"synthetic {a.workload} MV arrays, {params.grid_w}x{params.grid_h} grid, "
+                                   f"{a.frames} frames/GPU/step in {S} streams ({a.distinct} distinct frames tiled), "
+                                   f"params={a.params}",
+                       "frames_per_gpu": a.frames, "records_per_step_per_gpu": n_records,
+                       "bytes_per_step_per_gpu": alg_bytes, "parallelism": f"frame-sharded x{world}",
+                       "step": "scan kernel" if a.no_merge else "scan + stream-merge kernels" +
+                               (" + RCCL all_gather of segment lists" if world > 1 else "")},
+            "roofline": {"bound": "hbm", "kernel": "scan_frames_kernel", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes},
+            "cpu_baseline": cpu,
+            "motion_frames_in_batch": int(flags_host.sum()),
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    scanner.close()
+    del out
+
+
+def cpu_baseline(params, mv, off, gpu_flags, budget_s, workload):
+    """The C oracle (kind "port": our restatement of the reference's check_frame) timed on
+    this host's cores on a bounded sample: the `distinct` generated frames, scanned
+    repeatedly until ~budget_s seconds of wall time; frames split over all usable cores
+    (one private grid per thread, the reference's one-scanner-per-worker model)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_binding as ob     # checker / baseline only
+    cores = len(os.sched_getaffinity(0))
+    n = len(off) - 1
+    flags = ob.scan_frames(params, mv, off, None, nthreads=cores)       # warm-up + parity check
+    assert np.array_equal(flags, gpu_flags), "GPU flags differ from the oracle on the bench tile"
+    t0 = time.perf_counter()
+    ob.scan_frames(params, mv, off, None, nthreads=1)
+    t1 = time.perf_counter() - t0
+    reps, t_mt = 0, 0.0
+    t0 = time.perf_counter()
+    while True:
+        ob.scan_frames(params, mv, off, None, nthreads=cores)
+        reps += 1
+        t_mt = time.perf_counter() - t0
+        if t_mt > budget_s or reps >= 10000:
+            break
+    return {"value": n * reps / t_mt, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{n} distinct {workload} frames x {reps} passes ({t_mt:.1f} s wall), "
+                      f"oracle/mt_oracle.c scan, {cores} pthreads",
+            "value_1core": n / t1}
+
+
+if __name__ == "__main__":
+    main()

@@ -96,6 +96,14 @@ def load_library(path=None):
     if _lib is not None and path is None:
         return _lib
     p = path or LIB_PATH
+    # One HIP runtime per process: the PyTorch wheel bundles its own libamdhip64.so.7 /
+    # libhsa-runtime64.so.1 (same SONAMEs as /opt/rocm).  If libmtgpu.so pulled in the
+    # system copies first, a later `import torch` would find "No HIP GPUs".  Importing
+    # torch first makes both share torch's runtime; without torch the system ROCm is used.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(p):
         raise FileNotFoundError(
             f"{p} not found: build it with `make -C {os.path.join(PKG_DIR, 'csrc')}` "

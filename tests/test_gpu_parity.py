@@ -41,7 +41,9 @@ def assert_scan_parity(scanner, params, mv, off, has_sd):
 @pytest.mark.parametrize("cfg", ["code_defaults", "shipped_env"])
 @pytest.mark.parametrize("sub", [1, 2])
 def test_scan_1080p_stream(gpu_scanner_factory, cfg, sub):
-    kw = m.config.CODE_DEFAULTS if cfg == "code_defaults" else m.config.SHIPPED_ENV
+    kw = dict(m.config.CODE_DEFAULTS if cfg == "code_defaults" else m.config.SHIPPED_ENV)
+    if sub == 1:
+        kw["vectors_needed"] = 1               # one record per cell: a cell never collects 2 votes
     spec = synth.spec_1080p(seed=11 + sub, sub=sub)
     spec.events = synth.scripted_events(spec, 120)
     mv, off, pts, sd = synth.gen_stream(spec, 120)
@@ -179,9 +181,10 @@ def test_scan_device_resident_matches_host_path(gpu_scanner_factory):
     spec = synth.spec_1080p(seed=3, sub=1)
     spec.events = synth.scripted_events(spec, 64)
     mv, off, pts, sd = synth.gen_stream(spec, 64)
-    p = ob.params_from_config(1920, 1080)
+    p = ob.params_from_config(1920, 1080, vectors_needed=1)
     s = gpu_scanner_factory(p)
     want = ob.scan_frames(p, mv, off, sd)
+    assert want.sum() > 0
     d_mv = torch.from_numpy(mv.view(np.uint8).copy()).cuda()
     d_off = torch.from_numpy(off.astype(np.int64)).cuda()
     d_sd = torch.from_numpy(sd).cuda()
@@ -338,7 +341,7 @@ def test_end_to_end_stream_segments(gpu_scanner_factory):
     ticks = [spec.pts_ticks(i) for i in range(n)]
     tb = 1.0 / spec.tb_den
     duration = n / spec.fps
-    p = ob.params_from_config(1920, 1080)
+    p = ob.params_from_config(1920, 1080, vectors_needed=1)
     s = gpu_scanner_factory(p)
     pooled_gpu, pooled_cpu = [], []
     for (c0, c1, _) in m.make_chunks(duration, 6.0):
