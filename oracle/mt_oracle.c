@@ -279,7 +279,7 @@ int mto_merge_segments(const double *ts, int64_t n, const mt_merge_params *mp,
     }
     if (close_seg) {
       double s = seg_start - pad;                    /* :337 / :343 */
-      if (s < 0.0) s = 0.0;                          /* std::max(0.0, .) */
+      s = (0.0 < s) ? s : 0.0;                       /* std::max(0.0, s) == (a < b) ? b : a */
       double e = last + pad;                         /* :338 / :344 */
       if (dur < e) e = dur;                          /* :351 std::min(s.end, duration) */
       if (e < s) s = e;                              /* :352 std::min(s.start, s.end) */

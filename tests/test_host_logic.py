@@ -1,0 +1,112 @@
+"""CPU tests of the host-side mirror (motion-estimated-video-trimmer_amd/scanner.py,
+config.py, dist.py helpers) against the oracle.  No GPU needed."""
+import numpy as np
+import pytest
+
+import mvtrim_amd as m
+from mvtrim_amd import dist as mdist
+from mvtrim_amd import synth
+
+import oracle_binding as ob
+
+
+def test_params_from_config_matches_oracle():
+    """libmtgpu's host-side derivation (mtgpu_params_from_config) == the oracle's, over many
+    sizes / block settings / masks (reference src/motion_scanner.cpp:184-199)."""
+    rng = np.random.RandomState(0)
+    for _ in range(400):
+        w, h = int(rng.randint(1, 8000)), int(rng.randint(1, 5000))
+        sh = int(rng.randint(0, 7))
+        bs = int(rng.choice([1 << sh, 16, 8, 4, 1]))
+        vm = float(np.float32(rng.choice([0.0, 0.05, 0.1, 0.25, 0.5, 0.7, rng.rand()])))
+        kw = dict(mv_threshold_sq=float(rng.choice([16.0, 4.0, 0.0, 7.5])), block_size=bs, block_shift=sh,
+                  vectors_needed=int(rng.randint(-3, 600)), clusters_needed=int(rng.randint(-3, 50)),
+                  vertical_mask=vm)
+        try:
+            want = ob.params_from_config(w, h, **kw)
+        except ValueError:
+            with pytest.raises(m.MtgpuError):
+                m.ScanParams.from_config(w, h, **kw)
+            continue
+        assert m.ScanParams.from_config(w, h, **kw) == want
+
+
+def test_config_getters_follow_env(monkeypatch):
+    c = m.config
+    for k in ["MV_THRESHOLD_SQ", "BLOCK_SIZE", "BLOCK_SHIFT", "VECTORS_NEEDED", "CLUSTERS_NEEDED",
+              "VERTICAL_MASK", "MAX_GAP_SEC", "PADDING_SEC", "CHUNK_DURATION_SEC", "TARGET_FPS", "MIN_SAVINGS_PCT"]:
+        monkeypatch.delenv(k, raising=False)
+    # code defaults (include/motion_trim/config.hpp:56-125)
+    assert (c.mv_threshold_sq(), c.block_size(), c.block_shift(), c.vectors_needed(), c.clusters_needed()) == \
+        (16.0, 16, 4, 2, 2)
+    assert c.vertical_mask() == float(np.float32(0.05))
+    assert (c.max_gap_sec(), c.padding_sec(), c.chunk_duration_sec(), c.target_fps(), c.min_savings_pct()) == \
+        (5.0, 0.5, 30.0, 0.0, 5.0)
+    p = m.ScanParams.from_config(1920, 1080)
+    assert (p.mv_threshold_sq, p.vectors_needed, p.clusters_needed, p.vertical_margin) == (16.0, 2, 2, 3)
+    # shipped env file values (config/motion_trim.env:36,75,93,113,211)
+    monkeypatch.setenv("MV_THRESHOLD_SQ", "4.0")
+    monkeypatch.setenv("VECTORS_NEEDED", "4")
+    monkeypatch.setenv("TARGET_FPS", "10.0")
+    p = m.ScanParams.from_config(1920, 1080)
+    assert (p.mv_threshold_sq, p.vectors_needed) == (4.0, 4)
+    assert c.target_fps() == 10.0
+    monkeypatch.setenv("VECTORS_NEEDED", "260")          # uint8 cast
+    assert c.vectors_needed() == 4 and m.ScanParams.from_config(1920, 1080).vectors_needed == 4
+    mp = m.MergeParams(duration=60.0)
+    assert (mp.max_gap_sec, mp.padding_sec, mp.min_savings_pct) == (5.0, 0.5, 5.0)
+
+
+def test_frame_filter_and_chunks_match_oracle():
+    rng = np.random.RandomState(3)
+    for _ in range(200):
+        fps = float(rng.choice([25.0, 30.0, 29.97, 50.0, 60.0]))
+        tfps = float(rng.choice([0.0, 5.0, 10.0, 30.0, 100.0]))
+        skip = m.frame_skip(fps, tfps)
+        assert skip == ob.lib().mto_frame_skip(fps, tfps)
+        tb = 1.0 / 90000.0
+        n = int(rng.randint(0, 400))
+        first = int(rng.randint(0, 1000))
+        ticks = [int(round((first + i) * 90000 / fps)) for i in range(n)]
+        start = float(rng.rand() * 20)
+        end = start + float(rng.rand() * 10)
+        assert m.filter_frames(ticks, tb, start, end, skip) == ob.filter_frames(ticks, tb, start, end, skip)
+    for dur, ch in [(70.0, 30.0), (60.0, 30.0), (0.0, 30.0), (0.1, 60.0), (123.456, 7.5), (1e-9, 1.0)]:
+        assert m.make_chunks(dur, ch) == ob.chunks(dur, ch)
+
+
+def test_frame_batch_from_frames():
+    a = np.zeros(3, dtype=m.MV_DTYPE)
+    a["dst_x"] = [1, 2, 3]
+    b = m.FrameBatch.from_frames([None, a, np.zeros(0, dtype=m.MV_DTYPE), a[:1]], pts=[0.0, 0.1, 0.2, 0.3])
+    assert b.n_frames == 4 and b.frame_off.tolist() == [0, 0, 3, 3, 4]
+    assert b.has_sd.tolist() == [0, 1, 1, 1] and b.mv["dst_x"].tolist() == [1, 2, 3, 1]
+    assert m.MV_DTYPE.itemsize == 40 and b.mv.view(np.uint8).size == 160
+    raw = a.view(np.uint8).reshape(3, 40)
+    assert raw[1, 10] == 2 and raw[1, 11] == 0         # dst_x sits at byte 10 (AVMotionVector layout)
+
+
+def test_synth_stream_is_deterministic_and_shaped():
+    spec = synth.spec_1080p(seed=5)
+    spec.events = synth.scripted_events(spec, 40)
+    f1 = synth.gen_frame(spec, 7)
+    f2 = synth.gen_frame(spec, 7)
+    assert f1.tobytes() == f2.tobytes() and len(f1) == 32640 == spec.records_per_frame
+    assert synth.gen_frame(spec, 30) is None           # I-frame
+    assert spec.pts_seconds(301) == float(3000 * 301) * (1.0 / 90000.0)
+    assert synth.spec_4k().records_per_frame == 129600 and synth.spec_4k_fine().records_per_frame == 518400
+    assert np.abs(f1["dst_x"].astype(int) - f1["src_x"]).max() <= 32767
+
+
+def test_sharding_helpers():
+    for n, w in [(64, 8), (10, 3), (3, 8), (0, 4), (17, 1)]:
+        rs = [mdist.shard_range(n, w, r) for r in range(w)]
+        assert rs[0][0] == 0 and rs[-1][1] == n
+        assert all(rs[i][1] == rs[i + 1][0] for i in range(w - 1))
+        sizes = [b - a for a, b in rs]
+        assert max(sizes) - min(sizes) <= 1
+    off = np.concatenate([[0], np.cumsum([100, 0, 100, 100, 0, 0, 100, 400, 100, 100])])
+    cuts = mdist.shard_by_records(off, 4)
+    assert cuts[0][0] == 0 and cuts[-1][1] == 10 and all(cuts[i][1] == cuts[i + 1][0] for i in range(3))
+    recs = [int(off[b] - off[a]) for a, b in cuts]
+    assert sum(recs) == 1000 and max(recs) <= 500

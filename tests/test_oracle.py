@@ -1,0 +1,212 @@
+"""CPU tests of the oracle (oracle/mt_oracle.c) against the committed golden vectors:
+hand-derived known answers, the two segments recorded from the reference's own object
+code in SURVEY.md §8c, and a second independent numpy restatement.  No GPU needed."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import mvtrim_amd as m
+from mvtrim_amd import synth
+
+import oracle_binding as ob
+from np_model import check_frame_np
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def build_mvs(case):
+    rows = [list(r) for r in case.get("mvs", [])]
+    for cx, cy, dx, dy, n in case.get("hits", []):
+        x, y = 16 * cx + 8, 16 * cy + 8
+        rows += [[x - dx, y - dy, x, y]] * n
+    mv = np.zeros(len(rows), dtype=m.MV_DTYPE)
+    if rows:
+        a = np.array(rows, dtype=np.int64)
+        mv["src_x"], mv["src_y"], mv["dst_x"], mv["dst_y"] = a[:, 0], a[:, 1], a[:, 2], a[:, 3]
+    return mv
+
+
+def load_hand_cases():
+    g = json.load(open(os.path.join(GOLD, "check_frame_hand_cases.json")))
+    out = []
+    for c in g["cases"]:
+        kw = dict(g["base"])
+        kw.update(c.get("over", {}))
+        out.append((c["name"], kw, c))
+    return g, out
+
+
+def test_hand_case_params():
+    g, _ = load_hand_cases()
+    p = ob.params_from_config(**g["base"])
+    for k, v in g["expect_params"].items():
+        assert getattr(p, k) == v
+
+
+@pytest.mark.parametrize("name,kw,case", load_hand_cases()[1], ids=lambda x: x if isinstance(x, str) else None)
+def test_check_frame_hand_cases(name, kw, case):
+    p = ob.params_from_config(**kw)
+    mv = build_mvs(case)
+    sd = bool(case.get("has_sd", 1))
+    assert ob.check_frame(p, mv, sd) == case["expect"]
+    flag, centres, grid = ob.check_frame(p, mv, sd, count_centres=True)
+    assert (flag, centres) == (case["expect"], case["centres"])
+    assert check_frame_np(p, mv, sd) == (case["expect"], case["centres"])
+    # record order must not matter
+    if len(mv) > 1:
+        assert ob.check_frame(p, mv[::-1].copy(), sd) == case["expect"]
+
+
+def test_params_derivation_known_answers():
+    # SURVEY.md §8 table (reference src/motion_scanner.cpp:190-196)
+    for (w, h, kw), want in [((1920, 1080, {}), (120, 68, 3)), ((3840, 2160, {}), (240, 135, 6)),
+                             ((3840, 2160, dict(block_size=4, block_shift=2)), (960, 540, 27)),
+                             ((1280, 720, {}), (80, 45, 2)), ((16, 16, {}), (1, 1, 0))]:
+        p = ob.params_from_config(w, h, **kw)
+        assert (p.grid_w, p.grid_h, p.vertical_margin) == want
+    # :196 evaluates int16 * float in float32: 10 * 0.7f rounds to exactly 7.0f -> 7
+    # (in double, 10 * (double)0.7f = 6.99999988 -> 6)
+    assert np.float32(10) * np.float32(0.7) == np.float32(7.0)
+    assert int(10 * float(np.float32(0.7))) == 6
+    assert ob.params_from_config(160, 160, vertical_mask=0.7).vertical_margin == 7
+    # config.hpp:75 — VECTORS_NEEDED is cast to uint8
+    assert ob.params_from_config(160, 160, vectors_needed=256 + 7).vectors_needed == 7
+    assert ob.params_from_config(160, 160, vectors_needed=-1).vectors_needed == 255
+    # BLOCK_SIZE and BLOCK_SHIFT are independent knobs (:190-193 vs :255-256)
+    p = ob.params_from_config(1920, 1080, block_size=16, block_shift=5)
+    assert (p.grid_w, p.grid_h) == (60, 34)
+    with pytest.raises(ValueError):
+        ob.params_from_config(1920, 1080, block_shift=32)
+    with pytest.raises(ValueError):
+        ob.params_from_config(0, 0, block_size=0)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_oracle_vs_numpy_model_random(seed):
+    rng = np.random.RandomState(seed)
+    cfgs = [dict(), dict(vertical_mask=0.0), dict(vectors_needed=1, clusters_needed=1),
+            dict(vectors_needed=0), dict(mv_threshold_sq=float("nan")), dict(mv_threshold_sq=30.5),
+            dict(clusters_needed=-3), dict(vectors_needed=200), dict(block_size=8, block_shift=3)]
+    for (w, h) in [(320, 240), (1920, 1080), (48, 48), (1040, 64)]:
+        for kw in cfgs:
+            p = ob.params_from_config(w, h, **kw)
+            mv, off, sd = synth.random_frames(rng, 6, 1500, w, h)
+            flags = ob.scan_frames(p, mv, off, sd)
+            for f in range(6):
+                fr = mv[int(off[f]):int(off[f + 1])]
+                flag, centres, _ = ob.check_frame(p, fr, bool(sd[f]), count_centres=True)
+                assert (flag, centres) == check_frame_np(p, fr, bool(sd[f])), (w, h, kw, f)
+                assert flags[f] == flag          # early exit == full count vs max(1, clusters_needed)
+
+
+def test_scan_frames_threads_and_null_has_sd():
+    spec = synth.spec_1080p(seed=4, sub=1)
+    spec.events = synth.scripted_events(spec, 40)
+    mv, off, pts, sd = synth.gen_stream(spec, 40)
+    p = ob.params_from_config(1920, 1080, vectors_needed=1)
+    a = ob.scan_frames(p, mv, off, sd)
+    assert 0 < a.sum() < 40 and a[0] == 0 and a[30] == 0      # I-frames: no side data
+    for nt in (2, 3, 8, 64):
+        assert np.array_equal(ob.scan_frames(p, mv, off, sd, nthreads=nt), a)
+    assert np.array_equal(ob.scan_frames(p, mv, off, None), a)
+
+
+# ------------------------------------------------------------------ merge
+
+def load_merge_cases():
+    g = json.load(open(os.path.join(GOLD, "merge_hand_cases.json")))
+    return [(c["name"], dict(g["base"], **c.get("over", {})), c) for c in g["cases"]]
+
+
+@pytest.mark.parametrize("name,kw,case", load_merge_cases(), ids=lambda x: x if isinstance(x, str) else None)
+def test_merge_hand_cases(name, kw, case):
+    ts = case.get("ts")
+    if ts is None:
+        a, b, s = case["ts_range"]
+        ts = list(np.arange(a, b, s, dtype=np.float64))
+    mp = m.MergeParams(**kw)
+    seg, res = ob.pool_and_merge(ts, mp, False)
+    assert [list(x) for x in seg.tolist()] == case["segments"]
+    assert res["time_removed"] == case["time_removed"] and res["do_cut"] == case["do_cut"]
+    if "n_unique" in case:
+        assert res["n_timestamps"] == case["n_unique"]
+    job, jres = ob.pool_and_merge(ts, mp, True)
+    assert [list(x) for x in job.tolist()] == case["job"] and jres["n_segments"] == len(case["job"])
+    if kw["duration"] > 0 and ts:
+        assert res["saved_pct"] == pytest.approx(case["time_removed"] / kw["duration"] * 100.0, abs=1e-9)
+
+
+def test_merge_reproduces_reference_run_recorded_in_survey():
+    g = json.load(open(os.path.join(GOLD, "survey_segments.json")))
+    ts = []
+    for a, b in g["motion_frame_runs"]:
+        ts += [float(3000 * i) * (1.0 / g["tb_den"]) for i in range(a, b + 1)]
+    mp = m.MergeParams(duration=g["duration"], max_gap_sec=g["max_gap_sec"], padding_sec=g["padding_sec"],
+                       min_savings_pct=5.0)
+    seg, res = ob.pool_and_merge(ts[::-1], mp, True)
+    assert res["do_cut"] == 1
+    got = [["%.17g" % s, "%.17g" % e] for s, e in seg.tolist()]
+    assert got == g["segments_printed_17g"]
+
+
+def test_sort_unique_and_merge_input_checks():
+    assert ob.sort_unique([3.0, 1.0, 2.0, 1.0, 3.0]).tolist() == [1.0, 2.0, 3.0]
+    assert ob.sort_unique([]).size == 0
+    assert ob.sort_unique([-0.0, 0.0]).size == 1                    # std::unique uses ==
+    with pytest.raises(ValueError):
+        ob.sort_unique([1.0, float("nan")])
+    with pytest.raises(ValueError):
+        ob.merge_segments([2.0, 1.0], m.MergeParams(duration=10.0))   # must be sorted
+    with pytest.raises(ValueError):
+        ob.merge_segments([1.0, 1.0], m.MergeParams(duration=10.0))   # and unique
+
+
+def test_merge_sequential_python_model():
+    """The oracle's single pass vs a literal two-loop python transcription of the reference's
+    structure (push all segments, then clamp+sum) on random inputs: bit-equal."""
+    rng = np.random.RandomState(1)
+    for _ in range(200):
+        n = rng.randint(1, 60)
+        ts = np.unique(np.round(rng.rand(n) * 50, 3))
+        mp = m.MergeParams(duration=float(rng.choice([0.0, 20.0, 50.0, 80.0])), max_gap_sec=float(rng.rand() * 4),
+                           padding_sec=float(rng.rand() * 3), min_savings_pct=5.0)
+        segs, cur, last = [], ts[0], ts[0]
+        for t in ts[1:]:
+            if t - last > mp.max_gap_sec:
+                segs.append([max(0.0, cur - mp.padding_sec), last + mp.padding_sec])
+                cur = t
+            last = t
+        segs.append([max(0.0, cur - mp.padding_sec), last + mp.padding_sec])
+        out = 0.0
+        for s in segs:
+            s[1] = min(s[1], mp.duration)
+            s[0] = min(s[0], s[1])
+            out += s[1] - s[0]
+        removed = mp.duration - out
+        seg, res = ob.merge_segments(ts, mp, False)
+        assert seg.tolist() == [tuple(s) for s in segs] or [list(x) for x in seg.tolist()] == segs
+        assert res["time_removed"] == removed
+
+
+# ------------------------------------------------------------------ a6 / a7
+
+def test_frame_filter_and_chunks():
+    assert ob.lib().mto_frame_skip(30.0, 10.0) == 3 and ob.lib().mto_frame_skip(30.0, 0.0) == 1
+    assert ob.lib().mto_frame_skip(30.0, 30.0) == 1 and ob.lib().mto_frame_skip(25.0, 10.0) == 2
+    assert ob.lib().mto_frame_skip(30.0, 45.0) == 1
+    ticks = [3000 * i for i in range(300)]                        # 10 s at 30 fps, time_base 1/90000
+    tb = 1.0 / 90000.0
+    idx, pts = ob.filter_frames(ticks, tb, 0.0, 5.0, 1)
+    assert idx == list(range(150)) and pts[1] == 3000.0 * tb
+    # skip 3: the counter counts EVERY decoded frame of the call, 3rd, 6th, ... are analysed (:357)
+    idx, _ = ob.filter_frames(ticks, tb, 0.0, 1.0, 3)
+    assert idx == [2, 5, 8, 11, 14, 17, 20, 23, 26, 29]
+    # pre-roll after a backward seek is counted by the skip counter but dropped by pts < start (:364)
+    idx, _ = ob.filter_frames(ticks[50:], tb, 2.0, 3.0, 3)
+    assert [i + 50 for i in idx] == [61, 64, 67, 70, 73, 76, 79, 82, 85, 88]   # local 3rd,6th.. with pts in [2,3)
+    # chunks (pipeline.cpp:163-167)
+    assert ob.chunks(70.0, 30.0) == [(0.0, 30.0, 0), (30.0, 60.0, 1), (60.0, 70.0, 2)]
+    assert ob.chunks(60.0, 30.0) == [(0.0, 30.0, 0), (30.0, 60.0, 1)]
+    assert ob.chunks(0.0, 30.0) == []
