@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--params", default="code_defaults", choices=["code_defaults", "shipped_env"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample budget (0 = skip)")
     ap.add_argument("--no-merge", action="store_true", help="time the scan kernel alone")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo + --same-device rehearses the N>1 control flow on a 1-GPU box")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     return ap.parse_args()
 
 
@@ -68,10 +71,15 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
+    if a.same_device:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     # ---------------- synthetic input: `distinct` generated frames, tiled to `frames`
     spec, (W, H, gridkw) = make_spec(a.workload, seed=1000 + rank)
@@ -79,7 +87,7 @@ def main():
     mv, off, pts, sd = synth.gen_stream(spec, a.distinct)
     kw = dict(m.config.CODE_DEFAULTS if a.params == "code_defaults" else m.config.SHIPPED_ENV)
     kw.update(gridkw)
-    if spec.sub == 1 and a.workload != "4k_fine":
+    if spec.sub == 1:
         kw["vectors_needed"] = 1      # one record per cell can never collect 2 votes in a cell
     params = m.ScanParams.from_config(W, H, **kw)
     scanner = m.MotionScanner(params, device=local)
@@ -124,7 +132,10 @@ def main():
         seg, res = scanner.merge_streams_device(d_flags, d_pts, d_soff, d_mp, True, SEG_CAP)
         if world > 1:
             # the only exchange step of the path: per-GPU segment lists to every rank (RCCL over xGMI)
-            gathered = mdist.gather_segment_lists(seg, res, out=gathered)
+            if a.backend == "nccl":
+                gathered = mdist.gather_segment_lists(seg, res, out=gathered)
+            else:       # rehearsal only: gloo moves the lists through host memory
+                gathered = mdist.gather_segment_lists(seg.cpu(), res.cpu(), out=gathered)
         return seg, res
 
     for _ in range(a.warmup):
@@ -143,7 +154,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

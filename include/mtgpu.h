@@ -74,10 +74,10 @@ typedef struct mtgpu_plan {
   int32_t bands;           /* row bands per frame (1 = whole grid in one LDS tile) */
   int32_t band_rows;       /* analysed rows per band                               */
   int32_t lds_bytes;       /* dynamic LDS per workgroup                            */
-  int32_t counter_bits;    /* width of one LDS vote counter                        */
+  int32_t counter_bits;    /* bits per LDS vote counter: 32, or 2/4/8 packed+saturating */
   int32_t device;
   int32_t cu_count;
-  int32_t _pad;
+  int32_t chunk_rows;      /* centre rows per cluster-test chunk (mask buffer rows - 2) */
 } mtgpu_plan;
 int mtgpu_get_plan(const mtgpu_ctx *ctx, mtgpu_plan *out);
 

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -87,10 +88,19 @@ int validate_params(const mt_scan_params *p) {
   return MT_OK;
 }
 
-size_t lds_need(int rows, int gw, int W, int *cnt_words) {
-  size_t cw = ((size_t)(rows + 2) * (size_t)gw + 3u) & ~(size_t)3u;
+// LDS bytes of one workgroup: packed counters for (band_rows + 2) rows, a mask buffer for
+// (chunk_rows + 2) rows, the centre total.
+size_t lds_need(int band_rows, int chunk_rows, int gw, int W, int fb, int *cnt_words) {
+  const size_t fields = (size_t)(band_rows + 2) * (size_t)gw;
+  size_t cw = (fields * (size_t)fb + 31u) / 32u;
+  cw = (cw + 3u) & ~(size_t)3u;
   if (cnt_words) *cnt_words = (int)cw;
-  return cw * 4u + (size_t)(rows + 2) * (size_t)W * 8u + 16u;
+  return cw * 4u + (size_t)(chunk_rows + 2) * (size_t)W * 8u + 16u;
+}
+
+int env_int(const char *name, int dflt) {
+  const char *v = getenv(name);
+  return v ? atoi(v) : dflt;
 }
 
 int make_plan(mtgpu_ctx *c, int lds_max, int cu_count) {
@@ -106,29 +116,53 @@ int make_plan(mtgpu_ctx *c, int lds_max, int cu_count) {
   k.vec_need = p.vectors_needed;
   k.clust_need = p.clusters_needed < 1 ? 1u : (unsigned int)p.clusters_needed;
   k.W = (p.grid_w + 63) / 64;
-  const int R = k.y_hi - k.y_lo;
-  int rows = R < 1 ? 1 : R;
-  if (lds_need(rows, k.gw, k.W, nullptr) > (size_t)lds_max) {
-    // largest band that fits: need(r) is linear in r
-    const size_t per_row = (size_t)k.gw * 4u + (size_t)k.W * 8u;
-    long r = ((long)lds_max - 16 - 16) / (long)per_row - 2;
-    while (r >= 1 && lds_need((int)r, k.gw, k.W, nullptr) > (size_t)lds_max) --r;
-    if (r < 1)
-      return fail(MT_ERR_CAPACITY, "grid width %d: three counter rows do not fit %d bytes of LDS", k.gw, lds_max);
-    rows = (int)r;
+  const int R = (k.y_hi - k.y_lo) < 1 ? 1 : (k.y_hi - k.y_lo);
+  const size_t mask_row = (size_t)k.W * 8u;
+
+  // Counter form.  Small grids keep plain 32-bit adds (one fire-and-forget ds_add per vote);
+  // grids whose u32 tile would exceed 64 KB use packed fields saturating at vectors_needed,
+  // the narrowest of 2/4/8 bits that can hold it.  MTGPU_FORCE_FB overrides (experiments).
+  const int packed_fb = k.vec_need <= 3u ? 2 : (k.vec_need <= 15u ? 4 : 8);
+  int fb = lds_need(R, R, k.gw, k.W, 32, nullptr) <= 64u * 1024u ? 32 : packed_fb;
+  const int force = env_int("MTGPU_FORCE_FB", 0);
+  if (force == 32 || ((force == 2 || force == 4 || force == 8) && force >= packed_fb)) fb = force;
+
+  int band_rows = R, chunk_rows = R;
+  if (lds_need(R, R, k.gw, k.W, fb, nullptr) > (size_t)lds_max) {
+    // 1st choice: whole grid in one tile, phase 2 in row chunks through a smaller mask buffer
+    const size_t cnt_only = lds_need(R, -2, k.gw, k.W, fb, nullptr);   // counters + total
+    const long room = (long)lds_max - (long)cnt_only;
+    long ch = room / (long)mask_row - 2;
+    if (ch > R) ch = R;
+    if (ch >= 8 || ch >= R) {
+      chunk_rows = (int)ch;
+    } else {
+      // 2nd choice: row bands (each band re-reads the frame's records through L2 / Infinity Cache)
+      const size_t per_row = ((size_t)k.gw * (size_t)fb + 7u) / 8u + mask_row;
+      long r = ((long)lds_max - 64) / (long)per_row - 2;
+      while (r >= 1 && lds_need((int)r, (int)r, k.gw, k.W, fb, nullptr) > (size_t)lds_max) --r;
+      if (r < 1)
+        return fail(MT_ERR_CAPACITY, "grid width %d: three counter rows do not fit %d bytes of LDS", k.gw, lds_max);
+      band_rows = chunk_rows = (int)r;
+    }
   }
-  k.band_rows = rows;
-  k.bands = R < 1 ? 1 : (R + rows - 1) / rows;
-  k.mask_rows = rows + 2;
-  const size_t lds = lds_need(rows, k.gw, k.W, &k.cnt_words);
-  c->plan.block_threads = lds <= 40u * 1024u ? 256 : (lds <= 80u * 1024u ? 512 : 1024);
+  k.fb = fb;
+  k.band_rows = band_rows;
+  k.chunk_rows = chunk_rows;
+  k.bands = (R + band_rows - 1) / band_rows;
+  k.mask_rows = chunk_rows + 2;
+  const size_t lds = lds_need(band_rows, chunk_rows, k.gw, k.W, fb, &k.cnt_words);
+  int block = lds <= 40u * 1024u ? 256 : (lds <= 80u * 1024u ? 512 : 1024);
+  const int fblock = env_int("MTGPU_FORCE_BLOCK", 0);
+  if (fblock == 256 || fblock == 512 || fblock == 1024) block = fblock;
+  c->plan.block_threads = block;
   c->plan.bands = k.bands;
   c->plan.band_rows = k.band_rows;
   c->plan.lds_bytes = (int)lds;
-  c->plan.counter_bits = 32;
+  c->plan.counter_bits = fb;
   c->plan.device = c->device;
   c->plan.cu_count = cu_count;
-  c->plan._pad = 0;
+  c->plan.chunk_rows = chunk_rows;
   return MT_OK;
 }
 

@@ -18,8 +18,10 @@ struct ScanK {
   int W;                   // 64-bit words per activity-mask row = ceil(gw / 64)
   int bands;               // row bands per frame
   int band_rows;           // analysed rows per band
-  int cnt_words;           // LDS counter words per workgroup ((band_rows + 2) * gw, padded to 4)
-  int mask_rows;           // band_rows + 2
+  int fb;                  // bits per LDS vote counter: 32 (plain add) or 2/4/8 (saturating CAS)
+  int chunk_rows;          // centre rows per phase-2 chunk (mask buffer holds chunk_rows + 2 rows)
+  int cnt_words;           // LDS counter words per workgroup ((band_rows + 2) * gw fields, padded to 4)
+  int mask_rows;           // chunk_rows + 2
 };
 
 struct ScanLaunch {

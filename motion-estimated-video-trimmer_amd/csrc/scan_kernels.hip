@@ -3,19 +3,27 @@
 // stencil work: HBM-read bound, no MFMA.
 //
 // Work item = (frame, row band).  One workgroup per item:
-//   phase 0  zero the band's vote counters in LDS           (:229 memset)
+//   phase 0  zero the band's vote counters in LDS                  (:229 memset)
 //   phase 1  stream the frame's packed 40-byte records, one record per lane and
 //            load (bytes 4..15 of each record = w,h,src_x,src_y,dst_x,dst_y),
-//            threshold on |d|^2, map dst to a cell, LDS atomic vote (:242-268)
-//   phase 2a one wave per (row, 64-cell word): `count >= vectors_needed`
-//            -> __ballot -> 64-bit row masks in LDS           (:282)
-//   phase 2b one lane per (row, word): shifted-mask 4-neighbour test,
-//            __popcll, LDS reduction, compare with clusters_needed (:277-293)
+//            threshold on |d|^2, map dst to a cell, vote in LDS     (:242-268)
+//   phase 2  per chunk of rows:
+//     2a     one wave per (row, 64-cell word): `count >= vectors_needed`
+//            -> __ballot -> 64-bit row masks in LDS                  (:282)
+//     2b     one lane per (row, word): shifted-mask 4-neighbour test,
+//            __popcll, LDS reduction                                 (:277-293)
+//   compare the centre count with max(1, clusters_needed)           (:288)
 //
-// The u8 saturation at 255 of the reference (:265-266) is unobservable (only
-// `>= vectors_needed`, vectors_needed <= 255, is ever tested), so the 32-bit LDS
-// counters are bit-exact.  The early `return true` (:288-289) does not change the
-// value: result = (#centre cells >= max(1, clusters_needed)).
+// Vote counters come in two forms (template FB = bits per cell):
+//   FB = 32  plain `ds_add_u32`.  The reference's u8 saturation at 255 (:265-266) is
+//            unobservable (only `>= vectors_needed`, vectors_needed <= 255, is tested),
+//            so 32-bit counts are bit-exact.
+//   FB = 2/4/8  packed fields saturating AT vectors_needed (<= 2^FB - 1) via an LDS
+//            compare-and-swap loop: cell active <=> field == vectors_needed.  16x / 8x /
+//            4x less LDS, so big grids (4K, 960x540) stay in one LDS tile and every
+//            record is read from HBM once.
+// The early `return true` (:288-289) does not change the value:
+// result = (#centre cells >= max(1, clusters_needed)).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -33,7 +41,36 @@ __device__ __forceinline__ u32x3 load_fields(const unsigned char *rec) {
   return __builtin_nontemporal_load(reinterpret_cast<const u32x3_a4 *>(rec + 4));
 }
 
+template <int FB>
+__device__ __forceinline__ void bump(unsigned int *cnt, unsigned int cell, unsigned int cap) {
+  if constexpr (FB == 32) {
+    atomicAdd(&cnt[cell], 1u);
+  } else {
+    constexpr unsigned int FM = (1u << FB) - 1u;
+    const unsigned int bit = cell * FB;
+    unsigned int *w = &cnt[bit >> 5];
+    const unsigned int sh = bit & 31u;
+    unsigned int old = *w;                                   // once saturated: a plain read
+    while (((old >> sh) & FM) < cap) {
+      const unsigned int seen = atomicCAS(w, old, old + (1u << sh));
+      if (seen == old) break;
+      old = seen;
+    }
+  }
+}
+
+template <int FB>
+__device__ __forceinline__ unsigned int count_of(const unsigned int *cnt, unsigned int cell) {
+  if constexpr (FB == 32) {
+    return cnt[cell];
+  } else {
+    const unsigned int bit = cell * FB;
+    return (cnt[bit >> 5] >> (bit & 31u)) & ((1u << FB) - 1u);
+  }
+}
+
 // Threshold + cell mapping + vote for one record (src/motion_scanner.cpp:246-267).
+template <int FB>
 __device__ __forceinline__ void vote(const u32x3 d, const ScanK &k, int t0, int t1,
                                      unsigned int *cnt) {
   const int src_x = (int)d.x >> 16;
@@ -49,10 +86,10 @@ __device__ __forceinline__ void vote(const u32x3 d, const ScanK &k, int t0, int 
   const int gy = dst_y >> k.shift;
   const bool in = (mag >= k.thr) & (gx >= 0) & (gx < k.gw) & (gy >= k.y_lo) & (gy < k.y_hi) &
                   (gy >= t0) & (gy < t1);
-  if (in) atomicAdd(&cnt[(gy - t0) * k.gw + gx], 1u);
+  if (in) bump<FB>(cnt, (unsigned int)((gy - t0) * k.gw + gx), k.vec_need);
 }
 
-template <int BLOCK, int UNROLL>
+template <int BLOCK, int UNROLL, int FB>
 __global__ __launch_bounds__(BLOCK) void scan_frames_kernel(
     const unsigned char *__restrict__ mv, unsigned long long n_records,
     const unsigned long long *__restrict__ frame_off, const unsigned char *__restrict__ has_sd,
@@ -81,17 +118,16 @@ __global__ __launch_bounds__(BLOCK) void scan_frames_kernel(
   const int trows = t1 - t0;                   // may be <= 0 for an empty analysed range
   const int W = k.W;
 
-  unsigned int *cnt = lds;                                         // [trows][gw]
+  unsigned int *cnt = lds;                                         // packed [trows][gw] fields
   unsigned long long *mask =
-      reinterpret_cast<unsigned long long *>(lds + k.cnt_words);   // [trows+2][W]
+      reinterpret_cast<unsigned long long *>(lds + k.cnt_words);   // [chunk_rows+2][W]
   unsigned int *total = reinterpret_cast<unsigned int *>(mask + (size_t)k.mask_rows * W);
 
-  // ---- phase 0: zero counters, mask halo rows, total
+  // ---- phase 0: zero counters and the centre total
   {
     u32x4 *c4 = reinterpret_cast<u32x4 *>(cnt);
     const int n4 = k.cnt_words >> 2;
     for (int i = tid; i < n4; i += BLOCK) c4[i] = (u32x4){0u, 0u, 0u, 0u};
-    for (int i = tid; i < k.mask_rows * W; i += BLOCK) mask[i] = 0ull;
     if (tid == 0) *total = 0u;
   }
   __syncthreads();
@@ -107,52 +143,56 @@ __global__ __launch_bounds__(BLOCK) void scan_frames_kernel(
 #pragma unroll
       for (int u = 0; u < UNROLL; ++u) d[u] = load_fields(base + (i + (unsigned long long)u * BLOCK) * 40ull);
 #pragma unroll
-      for (int u = 0; u < UNROLL; ++u) vote(d[u], k, t0, t1, cnt);
+      for (int u = 0; u < UNROLL; ++u) vote<FB>(d[u], k, t0, t1, cnt);
     }
-    for (; i < n; i += BLOCK) vote(load_fields(base + i * 40ull), k, t0, t1, cnt);
+    for (; i < n; i += BLOCK) vote<FB>(load_fields(base + i * 40ull), k, t0, t1, cnt);
   }
   __syncthreads();
 
-  // ---- phase 2a: activity masks, one wave per (tracked row, word)
-  if (trows > 0) {
-    const int lane = tid & 63, wave = tid >> 6;
-    const int ntask = trows * W;
-    for (int t = wave; t < ntask; t += BLOCK / 64) {
-      const int row = t / W, w = t - row * W;
-      const int x = w * 64 + lane;
-      const bool on = (x < k.gw) && (cnt[row * k.gw + x] >= k.vec_need);
-      const unsigned long long m = __ballot(on);
-      // mask row j holds grid row c0-1+j; tracked local row `row` is grid row t0+row
-      if (lane == 0) mask[(size_t)(row + t0 - c0 + 1) * W + w] = m;
-    }
-  }
-  __syncthreads();
-
-  // ---- phase 2b: centre cells with an active 4-neighbour
-  {
-    const int crows = c1 - c0;
-    const int ntask = crows > 0 ? crows * W : 0;
-    unsigned int local = 0;
-    for (int t = tid; t < ntask; t += BLOCK) {
-      const int r = t / W, w = t - r * W;      // centre row c0 + r  -> mask row r + 1
-      const unsigned long long *mr = mask + (size_t)(r + 1) * W;
-      const unsigned long long m = mr[w];
-      if (m == 0ull) continue;
-      const unsigned long long up = mr[w - W], dn = mr[w + W];
-      const unsigned long long lcarry = (w > 0) ? (mr[w - 1] >> 63) : 0ull;
-      const unsigned long long rcarry = (w + 1 < W) ? (mr[w + 1] << 63) : 0ull;
-      const unsigned long long nb = (m << 1) | lcarry | (m >> 1) | rcarry | up | dn;
-      // centres are x in [1, gw-2]  (:280)
-      const int lo = max(1 - w * 64, 0), hi = min(k.gw - 1 - w * 64, 64);   // bits [lo,hi)
-      unsigned long long valid = 0ull;
-      if (hi > lo) {
-        valid = (hi >= 64) ? ~0ull : ((1ull << hi) - 1ull);
-        valid &= ~((1ull << lo) - 1ull);
+  // ---- phase 2: chunks of centre rows [c0+q0, c0+q0+qn); mask row j <-> grid row c0+q0-1+j
+  const int crows = c1 - c0;
+  unsigned int local = 0;
+  for (int q0 = 0; q0 < crows; q0 += k.chunk_rows) {
+    const int qn = min(k.chunk_rows, crows - q0);
+    {  // 2a: activity masks, one wave per (mask row, word)
+      const int lane = tid & 63, wave = tid >> 6;
+      const int ntask = (qn + 2) * W;
+      for (int t = wave; t < ntask; t += BLOCK / 64) {
+        const int j = t / W, w = t - j * W;
+        const int g = c0 + q0 - 1 + j;                 // grid row of this mask row
+        const int x = w * 64 + lane;
+        bool on = false;
+        if (g >= t0 && g < t1 && x < k.gw)             // outside the grid = inactive
+          on = count_of<FB>(cnt, (unsigned int)((g - t0) * k.gw + x)) >= k.vec_need;
+        const unsigned long long m = __ballot(on);
+        if (lane == 0) mask[(size_t)j * W + w] = m;
       }
-      local += (unsigned int)__popcll(m & nb & valid);
     }
-    if (local) atomicAdd(total, local);
+    __syncthreads();
+    {  // 2b: centre cells with an active 4-neighbour
+      const int ntask = qn * W;
+      for (int t = tid; t < ntask; t += BLOCK) {
+        const int r = t / W, w = t - r * W;            // centre row c0+q0+r -> mask row r+1
+        const unsigned long long *mr = mask + (size_t)(r + 1) * W;
+        const unsigned long long m = mr[w];
+        if (m == 0ull) continue;
+        const unsigned long long up = mr[w - W], dn = mr[w + W];
+        const unsigned long long lcarry = (w > 0) ? (mr[w - 1] >> 63) : 0ull;
+        const unsigned long long rcarry = (w + 1 < W) ? (mr[w + 1] << 63) : 0ull;
+        const unsigned long long nb = (m << 1) | lcarry | (m >> 1) | rcarry | up | dn;
+        // centres are x in [1, gw-2]  (:280)
+        const int lo = max(1 - w * 64, 0), hi = min(k.gw - 1 - w * 64, 64);   // bits [lo,hi)
+        unsigned long long valid = 0ull;
+        if (hi > lo) {
+          valid = (hi >= 64) ? ~0ull : ((1ull << hi) - 1ull);
+          valid &= ~((1ull << lo) - 1ull);
+        }
+        local += (unsigned int)__popcll(m & nb & valid);
+      }
+    }
+    __syncthreads();                                   // masks are rewritten by the next chunk
   }
+  if (local) atomicAdd(total, local);
   __syncthreads();
 
   if (tid == 0) {
@@ -180,9 +220,9 @@ __global__ void finalize_flags_kernel(const unsigned long long *__restrict__ fra
 
 // ------------------------------------------------------------------ launchers
 
-template <int BLOCK>
-static hipError_t launch_block(const ScanLaunch &L) {
-  auto kern = scan_frames_kernel<BLOCK, 4>;
+template <int BLOCK, int FB>
+static hipError_t launch_one(const ScanLaunch &L) {
+  auto kern = scan_frames_kernel<BLOCK, 4, FB>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, L.lds_bytes);
   if (e != hipSuccess) return e;
@@ -196,6 +236,17 @@ static hipError_t launch_block(const ScanLaunch &L) {
     if (e != hipSuccess) return e;
   }
   return hipSuccess;
+}
+
+template <int BLOCK>
+static hipError_t launch_block(const ScanLaunch &L) {
+  switch (L.k.fb) {
+    case 32: return launch_one<BLOCK, 32>(L);
+    case 8: return launch_one<BLOCK, 8>(L);
+    case 4: return launch_one<BLOCK, 4>(L);
+    case 2: return launch_one<BLOCK, 2>(L);
+    default: return hipErrorInvalidValue;
+  }
 }
 
 hipError_t launch_scan(const ScanLaunch &L) {

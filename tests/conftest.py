@@ -32,8 +32,23 @@ def gpu_scanner_factory():
     import mvtrim_amd as m
     made = []
 
-    def make(params):
-        s = m.MotionScanner(params, device=0)
+    def make(params, force_fb=None, force_block=None):
+        """force_fb / force_block select a counter form / workgroup size through the
+        library's MTGPU_FORCE_FB / MTGPU_FORCE_BLOCK experiment knobs (read at create time)."""
+        old = {k: os.environ.get(k) for k in ("MTGPU_FORCE_FB", "MTGPU_FORCE_BLOCK")}
+        try:
+            for k, v in (("MTGPU_FORCE_FB", force_fb), ("MTGPU_FORCE_BLOCK", force_block)):
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = str(v)
+            s = m.MotionScanner(params, device=0)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
         made.append(s)
         return s
 

@@ -58,39 +58,52 @@ def test_scan_1080p_stream(gpu_scanner_factory, cfg, sub):
     assert np.array_equal(got2, want)
 
 
-def test_scan_4k_stream(gpu_scanner_factory):
+@pytest.mark.parametrize("force_fb", [None, 32])
+def test_scan_4k_stream(gpu_scanner_factory, force_fb):
     spec = synth.spec_4k(seed=5)
     spec.events = synth.scripted_events(spec, 16)
     spec.events.append(synth.Event(3, 9, 100, 60, 4, 3, 9, -5))
     mv, off, pts, sd = synth.gen_stream(spec, 16)
     p = ob.params_from_config(3840, 2160)
     assert (p.grid_w, p.grid_h, p.vertical_margin) == (240, 135, 6)
-    s = gpu_scanner_factory(p)
+    s = gpu_scanner_factory(p, force_fb=force_fb)
     want = assert_scan_parity(s, p, mv, off, sd)
     assert want.sum() >= 6
 
 
-def test_scan_4k_fine_grid_multiband(gpu_scanner_factory):
-    """960x540 grid (BLOCK_SIZE=4, SHIFT=2): the vote grid exceeds LDS -> row bands."""
+@pytest.mark.parametrize("force_fb", [None, 8, 32])
+def test_scan_4k_fine_grid(gpu_scanner_factory, force_fb):
+    """960x540 grid (BLOCK_SIZE=4, SHIFT=2).  Default plan: 2-bit packed saturating counters,
+    whole grid in one LDS tile, cluster test in row chunks.  force_fb=8: 8-bit fields -> row
+    bands; force_fb=32: plain u32 counters -> many row bands."""
     spec = synth.spec_4k_fine(seed=9)
-    spec.events = [synth.Event(1, 3, 300, 200, 6, 6, 9, 3),      # inside one band
-                   synth.Event(2, 4, 500, 27, 5, 1, -7, 0)]      # single row at y_min
+    spec.events = [synth.Event(1, 3, 300, 200, 6, 6, 9, 3),
+                   synth.Event(2, 4, 500, 27, 5, 1, -7, 0),       # single row at y_min
+                   synth.Event(1, 4, 100, 250, 3, 120, 9, 0)]     # tall: crosses chunk / band seams
     mv, off, pts, sd = synth.gen_stream(spec, 5)
-    kw = dict(block_size=4, block_shift=2)
+    kw = dict(block_size=4, block_shift=2, vectors_needed=1)   # one record per 4x4 cell
     p = ob.params_from_config(3840, 2160, **kw)
     assert (p.grid_w, p.grid_h, p.vertical_margin) == (960, 540, 27)
-    s = gpu_scanner_factory(p)
-    assert s.plan["bands"] > 1
-    assert_scan_parity(s, p, mv, off, sd)
+    s = gpu_scanner_factory(p, force_fb=force_fb)
+    plan = s.plan
+    if force_fb is None:
+        assert plan["counter_bits"] == 2 and plan["bands"] == 1 and plan["chunk_rows"] < 486
+    else:
+        assert plan["counter_bits"] == force_fb and plan["bands"] > 1
+    want = assert_scan_parity(s, p, mv, off, sd)
+    assert want.sum() >= 3
 
 
-def test_fine_grid_cluster_across_band_seam(gpu_scanner_factory):
-    """Two active cells stacked vertically exactly on a band seam: each band must see the
-    other's row as a neighbour (halo rows)."""
+@pytest.mark.parametrize("force_fb", [None, 4, 8, 32])
+def test_fine_grid_cluster_across_seams(gpu_scanner_factory, force_fb):
+    """Two active cells stacked vertically exactly on a chunk seam / band seam: each side must
+    see the other's row as a neighbour (halo rows)."""
     p = ob.params_from_config(3840, 2160, block_size=4, block_shift=2, vectors_needed=1, clusters_needed=2)
-    s = gpu_scanner_factory(p)
-    band_rows = s.plan["band_rows"]
-    seam = p.vertical_margin + band_rows          # first centre row of band 1
+    s = gpu_scanner_factory(p, force_fb=force_fb)
+    plan = s.plan
+    step = plan["band_rows"] if plan["bands"] > 1 else plan["chunk_rows"]
+    assert step < 486
+    seam = p.vertical_margin + step               # first centre row of the second band / chunk
     frames = []
     for (ya, yb) in [(seam - 1, seam), (seam, seam + 1), (seam - 2, seam - 1), (seam - 1, seam + 1)]:
         mv = np.zeros(2, dtype=m.MV_DTYPE)
@@ -102,6 +115,37 @@ def test_fine_grid_cluster_across_band_seam(gpu_scanner_factory):
     b = m.FrameBatch.from_frames(frames)
     want = assert_scan_parity(s, p, b.mv, b.frame_off, b.has_sd)
     assert list(want) == [1, 1, 1, 0]
+
+
+@pytest.mark.parametrize("force_fb", [2, 4, 8])
+@pytest.mark.parametrize("vec", [1, 2, 3, 4, 15, 16, 255])
+def test_packed_counter_forms(gpu_scanner_factory, force_fb, vec):
+    """Every packed counter width on a 1080p grid, with heavy same-cell contention (CAS loop)
+    and cells sitting exactly at vectors_needed-1 / vectors_needed / far above."""
+    if vec > (1 << force_fb) - 1:
+        pytest.skip("field too narrow for this vectors_needed (the planner never picks it)")
+    p = ob.params_from_config(1920, 1080, vectors_needed=vec, clusters_needed=2)
+    s = gpu_scanner_factory(p, force_fb=force_fb)
+    assert s.plan["counter_bits"] == force_fb
+    rng = np.random.RandomState(vec * 10 + force_fb)
+    frames = []
+    for trial in range(24):
+        cells = [(40 + 2 * (trial % 3), 30), (41 + 2 * (trial % 3), 30), (60, 20 + trial % 5), (60, 21 + trial % 5)]
+        parts = []
+        for ci, (cx, cy) in enumerate(cells):
+            n = [vec - 1, vec, vec + 1, 4 * vec + 300][rng.randint(0, 4)]
+            a = np.zeros(max(n, 0), dtype=m.MV_DTYPE)
+            a["dst_x"], a["dst_y"] = 16 * cx + rng.randint(0, 16, size=len(a)), 16 * cy + rng.randint(0, 16, size=len(a))
+            a["src_x"], a["src_y"] = a["dst_x"] - 7, a["dst_y"] + 3
+            parts.append(a)
+        fr = np.concatenate(parts)
+        frames.append(fr[rng.permutation(len(fr))])
+    b = m.FrameBatch.from_frames(frames)
+    want = assert_scan_parity(s, p, b.mv, b.frame_off, b.has_sd)
+    assert 0 < want.sum() < len(want)
+    # ragged random frames with hot spots as well
+    mv, off, sd = synth.random_frames(rng, 32, 4000, 1920, 1080, hot=0.7)
+    assert_scan_parity(s, p, mv, off, sd)
 
 
 # ------------------------------------------------------------------ scan: edge cases
@@ -130,13 +174,14 @@ EDGE_CFGS = [
 ]
 
 
+@pytest.mark.parametrize("force_fb", [None, 8])
 @pytest.mark.parametrize("width,height,kw", EDGE_CFGS)
-def test_scan_edge_configs(gpu_scanner_factory, width, height, kw):
+def test_scan_edge_configs(gpu_scanner_factory, width, height, kw, force_fb):
     import zlib
     rng = np.random.RandomState(zlib.crc32(repr((width, height, sorted(kw.items()))).encode()) % (2 ** 31))
     p = ob.params_from_config(width, height, **kw)
     assert m.ScanParams.from_config(width, height, **kw) == p or np.isnan(p.mv_threshold_sq)
-    s = gpu_scanner_factory(p)
+    s = gpu_scanner_factory(p, force_fb=force_fb)
     mv, off, sd = synth.random_frames(rng, 48, 3000, width, height)
     junk_padding(mv, rng)
     want = assert_scan_parity(s, p, mv, off, sd)
