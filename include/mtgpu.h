@@ -74,10 +74,12 @@ typedef struct mtgpu_plan {
   int32_t bands;           /* row bands per frame (1 = whole grid in one LDS tile) */
   int32_t band_rows;       /* analysed rows per band                               */
   int32_t lds_bytes;       /* dynamic LDS per workgroup                            */
-  int32_t counter_bits;    /* bits per LDS vote counter: 32, or 2/4/8 packed+saturating */
+  int32_t counter_bits;    /* bits per LDS vote counter: 32, or 1/2/4/8 packed           */
   int32_t device;
   int32_t cu_count;
   int32_t chunk_rows;      /* centre rows per cluster-test chunk (mask buffer rows - 2) */
+  int32_t counter_mode;    /* 0 = 32-bit add, 1 = thermometer (OR), 2 = 8-bit binary (CAS) */
+  int32_t _pad;
 } mtgpu_plan;
 int mtgpu_get_plan(const mtgpu_ctx *ctx, mtgpu_plan *out);
 

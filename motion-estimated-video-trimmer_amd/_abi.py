@@ -54,7 +54,8 @@ class MergeResultC(C.Structure):
 class PlanC(C.Structure):
     _fields_ = [("block_threads", C.c_int32), ("bands", C.c_int32), ("band_rows", C.c_int32),
                 ("lds_bytes", C.c_int32), ("counter_bits", C.c_int32), ("device", C.c_int32),
-                ("cu_count", C.c_int32), ("chunk_rows", C.c_int32)]
+                ("cu_count", C.c_int32), ("chunk_rows", C.c_int32),
+                ("counter_mode", C.c_int32), ("_pad", C.c_int32)]
 
 
 assert C.sizeof(ScanParamsC) == 32 and C.sizeof(MergeResultC) == 40

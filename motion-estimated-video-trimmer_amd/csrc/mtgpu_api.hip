@@ -119,13 +119,22 @@ int make_plan(mtgpu_ctx *c, int lds_max, int cu_count) {
   const int R = (k.y_hi - k.y_lo) < 1 ? 1 : (k.y_hi - k.y_lo);
   const size_t mask_row = (size_t)k.W * 8u;
 
-  // Counter form.  Small grids keep plain 32-bit adds (one fire-and-forget ds_add per vote);
-  // grids whose u32 tile would exceed 64 KB use packed fields saturating at vectors_needed,
-  // the narrowest of 2/4/8 bits that can hold it.  MTGPU_FORCE_FB overrides (experiments).
-  const int packed_fb = k.vec_need <= 3u ? 2 : (k.vec_need <= 15u ? 4 : 8);
-  int fb = lds_need(R, R, k.gw, k.W, 32, nullptr) <= 64u * 1024u ? 32 : packed_fb;
+  // Counter form (scan_kernels.hip).  Plain 32-bit adds whenever the whole tile fits LDS (the
+  // fastest and contention-proof form); otherwise packed thermometer fields, the narrowest of
+  // 1/2/4/8 bits >= vectors_needed; binary 8-bit CAS fields only for vectors_needed > 8.
+  // MTGPU_FORCE_FB = 32 | 1 | 2 | 4 | 8 | 108 (8-bit CAS) overrides, for tests and experiments.
+  const unsigned int vn = k.vec_need;
+  int packed_fb = vn <= 1u ? 1 : (vn <= 2u ? 2 : (vn <= 4u ? 4 : 8));
+  int packed_mode = vn <= 8u ? 1 : 2;
+  int fb = 32, mode = 0;
+  if (lds_need(R, R, k.gw, k.W, 32, nullptr) > (size_t)lds_max) { fb = packed_fb; mode = packed_mode; }
   const int force = env_int("MTGPU_FORCE_FB", 0);
-  if (force == 32 || ((force == 2 || force == 4 || force == 8) && force >= packed_fb)) fb = force;
+  if (force == 32) { fb = 32; mode = 0; }
+  else if (force == 108) { fb = 8; mode = 2; }
+  else if ((force == 1 || force == 2 || force == 4 || force == 8) && (unsigned int)force >= vn) { fb = force; mode = 1; }
+  else if (force == 1 || force == 2 || force == 4 || force == 8) { fb = packed_fb; mode = packed_mode; }
+  k.mode = mode;
+  k.active_min = mode == 1 ? ((1u << vn) - 1u) : vn;         // thermometer full / binary count
 
   int band_rows = R, chunk_rows = R;
   if (lds_need(R, R, k.gw, k.W, fb, nullptr) > (size_t)lds_max) {
@@ -152,7 +161,10 @@ int make_plan(mtgpu_ctx *c, int lds_max, int cu_count) {
   k.bands = (R + band_rows - 1) / band_rows;
   k.mask_rows = chunk_rows + 2;
   const size_t lds = lds_need(band_rows, chunk_rows, k.gw, k.W, fb, &k.cnt_words);
-  int block = lds <= 40u * 1024u ? 256 : (lds <= 80u * 1024u ? 512 : 1024);
+  // Workgroup size: 512 threads x 4 loads in flight per lane keep a CU's memory queue full at
+  // 4 workgroups/CU (measured +2.5 % over 256 on 1080p); tiles above 80 KB run 1 workgroup/CU
+  // and take all 16 waves.
+  int block = lds <= 80u * 1024u ? 512 : 1024;
   const int fblock = env_int("MTGPU_FORCE_BLOCK", 0);
   if (fblock == 256 || fblock == 512 || fblock == 1024) block = fblock;
   c->plan.block_threads = block;
@@ -163,6 +175,8 @@ int make_plan(mtgpu_ctx *c, int lds_max, int cu_count) {
   c->plan.device = c->device;
   c->plan.cu_count = cu_count;
   c->plan.chunk_rows = chunk_rows;
+  c->plan.counter_mode = mode;
+  c->plan._pad = 0;
   return MT_OK;
 }
 

@@ -18,7 +18,9 @@ struct ScanK {
   int W;                   // 64-bit words per activity-mask row = ceil(gw / 64)
   int bands;               // row bands per frame
   int band_rows;           // analysed rows per band
-  int fb;                  // bits per LDS vote counter: 32 (plain add) or 2/4/8 (saturating CAS)
+  int fb;                  // bits per LDS vote counter: 32, or 1/2/4/8 packed
+  int mode;                // 0 ADD32 (fb 32), 1 UNARY thermometer (vec_need <= fb), 2 CAS (fb 8)
+  unsigned int active_min; // cell active <=> field value >= active_min
   int chunk_rows;          // centre rows per phase-2 chunk (mask buffer holds chunk_rows + 2 rows)
   int cnt_words;           // LDS counter words per workgroup ((band_rows + 2) * gw fields, padded to 4)
   int mask_rows;           // chunk_rows + 2

@@ -14,14 +14,20 @@
 //            __popcll, LDS reduction                                 (:277-293)
 //   compare the centre count with max(1, clusters_needed)           (:288)
 //
-// Vote counters come in two forms (template FB = bits per cell):
-//   FB = 32  plain `ds_add_u32`.  The reference's u8 saturation at 255 (:265-266) is
-//            unobservable (only `>= vectors_needed`, vectors_needed <= 255, is tested),
-//            so 32-bit counts are bit-exact.
-//   FB = 2/4/8  packed fields saturating AT vectors_needed (<= 2^FB - 1) via an LDS
-//            compare-and-swap loop: cell active <=> field == vectors_needed.  16x / 8x /
-//            4x less LDS, so big grids (4K, 960x540) stay in one LDS tile and every
-//            record is read from HBM once.
+// Vote counters come in three forms (template FB = bits per cell, MODE):
+//   ADD32    FB = 32, plain fire-and-forget `ds_add_u32`.  The reference's u8 saturation at
+//            255 (:265-266) is unobservable (only `>= vectors_needed`, vectors_needed <= 255,
+//            is tested), so 32-bit counts are bit-exact.  Used whenever the tile fits LDS.
+//   UNARY    FB = 1/2/4/8 >= vectors_needed: each field is a thermometer code of
+//            min(votes, vectors_needed).  A vote reads the field, then sets the first clear
+//            bit with a returning `ds_or_rtn_b32`; if another lane set that bit first it
+//            moves to the next one.  No retry loop on contention (same-word ORs are
+//            serialised by the LDS unit), at most vectors_needed ORs per vote, and a
+//            saturated field costs one plain read.  cell active <=> bit vectors_needed-1 set.
+//   CAS8     FB = 8 binary field saturating at vectors_needed (9..255) via compare-and-swap.
+//            Only for unusually large VECTORS_NEEDED on grids too big for 32-bit counters.
+//   Packed forms need 32x..4x less LDS, so big grids (960x540) stay in one LDS tile and
+//   every record is read from HBM once.
 // The early `return true` (:288-289) does not change the value:
 // result = (#centre cells >= max(1, clusters_needed)).
 #include <hip/hip_runtime.h>
@@ -41,20 +47,33 @@ __device__ __forceinline__ u32x3 load_fields(const unsigned char *rec) {
   return __builtin_nontemporal_load(reinterpret_cast<const u32x3_a4 *>(rec + 4));
 }
 
-template <int FB>
+enum { MODE_ADD32 = 0, MODE_UNARY = 1, MODE_CAS = 2 };
+
+template <int FB, int MODE>
 __device__ __forceinline__ void bump(unsigned int *cnt, unsigned int cell, unsigned int cap) {
-  if constexpr (FB == 32) {
+  if constexpr (MODE == MODE_ADD32) {
     atomicAdd(&cnt[cell], 1u);
   } else {
-    constexpr unsigned int FM = (1u << FB) - 1u;
+    constexpr unsigned int FM = (FB >= 32) ? 0xffffffffu : ((1u << FB) - 1u);
     const unsigned int bit = cell * FB;
     unsigned int *w = &cnt[bit >> 5];
     const unsigned int sh = bit & 31u;
-    unsigned int old = *w;                                   // once saturated: a plain read
-    while (((old >> sh) & FM) < cap) {
-      const unsigned int seen = atomicCAS(w, old, old + (1u << sh));
-      if (seen == old) break;
-      old = seen;
+    unsigned int f = (*w >> sh) & FM;                        // once saturated: a plain read
+    if constexpr (MODE == MODE_UNARY) {
+      unsigned int j = (unsigned int)__popc(f);              // thermometer: bits 0..j-1 are set
+      while (j < cap) {
+        const unsigned int old = atomicOr(w, 1u << (sh + j));
+        f = (old >> sh) & FM;
+        if (((f >> j) & 1u) == 0u) break;                    // this lane set bit j: vote counted
+        j = (unsigned int)__popc(f);                         // somebody else did: next clear bit
+      }
+    } else {
+      unsigned int old = *w;
+      while (((old >> sh) & FM) < cap) {
+        const unsigned int seen = atomicCAS(w, old, old + (1u << sh));
+        if (seen == old) break;
+        old = seen;
+      }
     }
   }
 }
@@ -70,7 +89,7 @@ __device__ __forceinline__ unsigned int count_of(const unsigned int *cnt, unsign
 }
 
 // Threshold + cell mapping + vote for one record (src/motion_scanner.cpp:246-267).
-template <int FB>
+template <int FB, int MODE>
 __device__ __forceinline__ void vote(const u32x3 d, const ScanK &k, int t0, int t1,
                                      unsigned int *cnt) {
   const int src_x = (int)d.x >> 16;
@@ -86,10 +105,10 @@ __device__ __forceinline__ void vote(const u32x3 d, const ScanK &k, int t0, int 
   const int gy = dst_y >> k.shift;
   const bool in = (mag >= k.thr) & (gx >= 0) & (gx < k.gw) & (gy >= k.y_lo) & (gy < k.y_hi) &
                   (gy >= t0) & (gy < t1);
-  if (in) bump<FB>(cnt, (unsigned int)((gy - t0) * k.gw + gx), k.vec_need);
+  if (in) bump<FB, MODE>(cnt, (unsigned int)((gy - t0) * k.gw + gx), k.vec_need);
 }
 
-template <int BLOCK, int UNROLL, int FB>
+template <int BLOCK, int UNROLL, int FB, int MODE>
 __global__ __launch_bounds__(BLOCK) void scan_frames_kernel(
     const unsigned char *__restrict__ mv, unsigned long long n_records,
     const unsigned long long *__restrict__ frame_off, const unsigned char *__restrict__ has_sd,
@@ -143,9 +162,9 @@ __global__ __launch_bounds__(BLOCK) void scan_frames_kernel(
 #pragma unroll
       for (int u = 0; u < UNROLL; ++u) d[u] = load_fields(base + (i + (unsigned long long)u * BLOCK) * 40ull);
 #pragma unroll
-      for (int u = 0; u < UNROLL; ++u) vote<FB>(d[u], k, t0, t1, cnt);
+      for (int u = 0; u < UNROLL; ++u) vote<FB, MODE>(d[u], k, t0, t1, cnt);
     }
-    for (; i < n; i += BLOCK) vote<FB>(load_fields(base + i * 40ull), k, t0, t1, cnt);
+    for (; i < n; i += BLOCK) vote<FB, MODE>(load_fields(base + i * 40ull), k, t0, t1, cnt);
   }
   __syncthreads();
 
@@ -163,7 +182,7 @@ __global__ __launch_bounds__(BLOCK) void scan_frames_kernel(
         const int x = w * 64 + lane;
         bool on = false;
         if (g >= t0 && g < t1 && x < k.gw)             // outside the grid = inactive
-          on = count_of<FB>(cnt, (unsigned int)((g - t0) * k.gw + x)) >= k.vec_need;
+          on = count_of<FB>(cnt, (unsigned int)((g - t0) * k.gw + x)) >= k.active_min;
         const unsigned long long m = __ballot(on);
         if (lane == 0) mask[(size_t)j * W + w] = m;
       }
@@ -220,9 +239,9 @@ __global__ void finalize_flags_kernel(const unsigned long long *__restrict__ fra
 
 // ------------------------------------------------------------------ launchers
 
-template <int BLOCK, int FB>
+template <int BLOCK, int FB, int MODE>
 static hipError_t launch_one(const ScanLaunch &L) {
-  auto kern = scan_frames_kernel<BLOCK, 4, FB>;
+  auto kern = scan_frames_kernel<BLOCK, 4, FB, MODE>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, L.lds_bytes);
   if (e != hipSuccess) return e;
@@ -240,11 +259,14 @@ static hipError_t launch_one(const ScanLaunch &L) {
 
 template <int BLOCK>
 static hipError_t launch_block(const ScanLaunch &L) {
-  switch (L.k.fb) {
-    case 32: return launch_one<BLOCK, 32>(L);
-    case 8: return launch_one<BLOCK, 8>(L);
-    case 4: return launch_one<BLOCK, 4>(L);
-    case 2: return launch_one<BLOCK, 2>(L);
+  const int key = L.k.mode * 100 + L.k.fb;
+  switch (key) {
+    case MODE_ADD32 * 100 + 32: return launch_one<BLOCK, 32, MODE_ADD32>(L);
+    case MODE_UNARY * 100 + 1: return launch_one<BLOCK, 1, MODE_UNARY>(L);
+    case MODE_UNARY * 100 + 2: return launch_one<BLOCK, 2, MODE_UNARY>(L);
+    case MODE_UNARY * 100 + 4: return launch_one<BLOCK, 4, MODE_UNARY>(L);
+    case MODE_UNARY * 100 + 8: return launch_one<BLOCK, 8, MODE_UNARY>(L);
+    case MODE_CAS * 100 + 8: return launch_one<BLOCK, 8, MODE_CAS>(L);
     default: return hipErrorInvalidValue;
   }
 }

@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Interleaved A/B of scan-kernel launch plans in ONE process (guide rule 24): for each
+workload build one scanner per variant (MTGPU_FORCE_FB / MTGPU_FORCE_BLOCK), run the
+variants round-robin, report median / min kernel time and algorithmic GB/s.
+Usage: python scripts/ab_scan.py [workload ...]   (needs a GPU)"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+import mvtrim_amd as m  # noqa: E402
+from bench import make_spec  # noqa: E402
+from mvtrim_amd import synth  # noqa: E402
+
+VARIANTS = [("fb32", dict(MTGPU_FORCE_FB="32")), ("fb2", dict(MTGPU_FORCE_FB="2")),
+            ("fb32/b512", dict(MTGPU_FORCE_FB="32", MTGPU_FORCE_BLOCK="512")),
+            ("fb2/b512", dict(MTGPU_FORCE_FB="2", MTGPU_FORCE_BLOCK="512")),
+            ("fb2/b1024", dict(MTGPU_FORCE_FB="2", MTGPU_FORCE_BLOCK="1024")),
+            ("fb32/b1024", dict(MTGPU_FORCE_FB="32", MTGPU_FORCE_BLOCK="1024"))]
+FRAMES = {"1080p_dense8x8": 4096, "1080p_dense16": 16384, "4k_dense8x8": 1024, "4k_fine": 256}
+
+
+def main():
+    dev = torch.device("cuda", 0)
+    rounds = int(os.environ.get("AB_ROUNDS", "15"))
+    pan = os.environ.get("AB_PAN", "0") == "1"      # every MV above threshold (camera pan): vote-path stress
+    for wl in (sys.argv[1:] or list(FRAMES)):
+        spec, (W, H, gridkw) = make_spec(wl, seed=1)
+        distinct = 30
+        spec.events = synth.scripted_events(spec, distinct)
+        if pan:
+            spec.events = [synth.Event(0, distinct, 0, 0, spec.cells_x, spec.cells_y, 9, 3)]
+        mv, off, pts, sd = synth.gen_stream(spec, distinct)
+        kw = dict(m.config.CODE_DEFAULTS)
+        kw.update(gridkw)
+        if spec.sub == 1:
+            kw["vectors_needed"] = 1
+        params = m.ScanParams.from_config(W, H, **kw)
+        frames = FRAMES[wl]
+        reps = (frames + distinct - 1) // distinct
+        counts = np.tile(np.diff(off.astype(np.int64)), reps)[:frames]
+        off_big = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        d_mv = torch.from_numpy(mv.view(np.uint8).copy()).to(dev).repeat(reps)[: int(off_big[-1]) * 40].contiguous()
+        d_off = torch.from_numpy(off_big).to(dev)
+        alg = 40 * int(off_big[-1]) + 9 * frames
+        scanners = []
+        for name, env in VARIANTS:
+            for k in ("MTGPU_FORCE_FB", "MTGPU_FORCE_BLOCK"):
+                os.environ.pop(k, None)
+            os.environ.update(env)
+            try:
+                s = m.MotionScanner(params, 0)
+            except m.MtgpuError as e:
+                print(f"{wl:16s} {name:12s} skipped: {e}")
+                continue
+            plan = s.plan
+            scanners.append((name, s, plan, torch.empty(frames, dtype=torch.uint8, device=dev), []))
+        ref = None
+        for r in range(rounds + 2):
+            for name, s, plan, fl, times in scanners:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                s.check_frames_device(d_mv, d_off, None, fl)
+                e1.record()
+                torch.cuda.synchronize()
+                if r >= 2:
+                    times.append(e0.elapsed_time(e1))
+                if ref is None:
+                    ref = fl.clone()
+                assert torch.equal(fl, ref), f"{name} disagrees"
+        for name, s, plan, fl, times in scanners:
+            t = np.array(times)
+            print(f"{wl:16s}{' pan' if pan else ''} {name:12s} fb={plan['counter_bits']:2d} block={plan['block_threads']:4d} "
+                  f"bands={plan['bands']} lds={plan['lds_bytes']:6d}  median {np.median(t):.4f} ms  min {t.min():.4f} ms  "
+                  f"{alg / np.median(t) / 1e6:7.0f} GB/s (min-time {alg / t.min() / 1e6:7.0f})  motion={int(ref.sum())}")
+            s.close()
+
+
+if __name__ == "__main__":
+    main()

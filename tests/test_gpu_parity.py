@@ -71,11 +71,11 @@ def test_scan_4k_stream(gpu_scanner_factory, force_fb):
     assert want.sum() >= 6
 
 
-@pytest.mark.parametrize("force_fb", [None, 8, 32])
+@pytest.mark.parametrize("force_fb", [None, 2, 8, 108, 32])
 def test_scan_4k_fine_grid(gpu_scanner_factory, force_fb):
-    """960x540 grid (BLOCK_SIZE=4, SHIFT=2).  Default plan: 2-bit packed saturating counters,
-    whole grid in one LDS tile, cluster test in row chunks.  force_fb=8: 8-bit fields -> row
-    bands; force_fb=32: plain u32 counters -> many row bands."""
+    """960x540 grid (BLOCK_SIZE=4, SHIFT=2).  Default plan (vectors_needed 1): 1-bit packed
+    counters, whole grid in one LDS tile.  2: cluster test in row chunks.  8 / 108 (8-bit
+    thermometer / CAS fields) -> row bands; 32: plain u32 counters -> many row bands."""
     spec = synth.spec_4k_fine(seed=9)
     spec.events = [synth.Event(1, 3, 300, 200, 6, 6, 9, 3),
                    synth.Event(2, 4, 500, 27, 5, 1, -7, 0),       # single row at y_min
@@ -87,14 +87,16 @@ def test_scan_4k_fine_grid(gpu_scanner_factory, force_fb):
     s = gpu_scanner_factory(p, force_fb=force_fb)
     plan = s.plan
     if force_fb is None:
+        assert plan["counter_bits"] == 1 and plan["bands"] == 1 and plan["counter_mode"] == 1
+    elif force_fb == 2:
         assert plan["counter_bits"] == 2 and plan["bands"] == 1 and plan["chunk_rows"] < 486
     else:
-        assert plan["counter_bits"] == force_fb and plan["bands"] > 1
+        assert plan["counter_bits"] == force_fb % 100 and plan["bands"] > 1
     want = assert_scan_parity(s, p, mv, off, sd)
     assert want.sum() >= 3
 
 
-@pytest.mark.parametrize("force_fb", [None, 4, 8, 32])
+@pytest.mark.parametrize("force_fb", [2, 4, 8, 108, 32])
 def test_fine_grid_cluster_across_seams(gpu_scanner_factory, force_fb):
     """Two active cells stacked vertically exactly on a chunk seam / band seam: each side must
     see the other's row as a neighbour (halo rows)."""
@@ -117,16 +119,17 @@ def test_fine_grid_cluster_across_seams(gpu_scanner_factory, force_fb):
     assert list(want) == [1, 1, 1, 0]
 
 
-@pytest.mark.parametrize("force_fb", [2, 4, 8])
-@pytest.mark.parametrize("vec", [1, 2, 3, 4, 15, 16, 255])
+@pytest.mark.parametrize("force_fb", [1, 2, 4, 8, 108])
+@pytest.mark.parametrize("vec", [1, 2, 3, 4, 5, 8, 9, 16, 255])
 def test_packed_counter_forms(gpu_scanner_factory, force_fb, vec):
-    """Every packed counter width on a 1080p grid, with heavy same-cell contention (CAS loop)
-    and cells sitting exactly at vectors_needed-1 / vectors_needed / far above."""
-    if vec > (1 << force_fb) - 1:
-        pytest.skip("field too narrow for this vectors_needed (the planner never picks it)")
+    """Every packed counter form on a 1080p grid (thermometer 1/2/4/8 bits, 8-bit CAS = 108),
+    with heavy same-cell contention and cells sitting exactly at vectors_needed-1 /
+    vectors_needed / far above."""
+    if force_fb != 108 and vec > force_fb:
+        pytest.skip("thermometer field too narrow for this vectors_needed (the planner never picks it)")
     p = ob.params_from_config(1920, 1080, vectors_needed=vec, clusters_needed=2)
     s = gpu_scanner_factory(p, force_fb=force_fb)
-    assert s.plan["counter_bits"] == force_fb
+    assert s.plan["counter_bits"] == force_fb % 100 and s.plan["counter_mode"] == (2 if force_fb == 108 else 1)
     rng = np.random.RandomState(vec * 10 + force_fb)
     frames = []
     for trial in range(24):
@@ -174,7 +177,7 @@ EDGE_CFGS = [
 ]
 
 
-@pytest.mark.parametrize("force_fb", [None, 8])
+@pytest.mark.parametrize("force_fb", [None, 8, 108])
 @pytest.mark.parametrize("width,height,kw", EDGE_CFGS)
 def test_scan_edge_configs(gpu_scanner_factory, width, height, kw, force_fb):
     import zlib
