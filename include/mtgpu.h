@@ -139,6 +139,46 @@ int mtgpu_merge_streams_device(mtgpu_ctx *ctx, const uint8_t *d_flags, const dou
                                double *d_ts, mt_segment *d_seg, uint64_t seg_cap,
                                mt_merge_result *d_res, void *stream);
 
+/* ---------------------------------------------------------------------------
+ * Host dispatcher: pinned, multi-buffered H2D + scan pipeline on one device.
+ *
+ * Replaces the synchronous per-frame call inside the decode loop
+ * (src/motion_scanner.cpp:375-383) for a host decoder thread: the thread copies each
+ * AVFrame's MV side data into a pinned staging batch (the side data dies when the frame
+ * is reused, :347), submits the batch asynchronously (H2D copy, scan kernel, flags D2H on
+ * the batch's own stream) and keeps decoding into the next staging batch; results are
+ * collected in submission order.  `n_buffers` batches bound the memory in flight
+ * (back-pressure: acquire fails with MT_ERR_BUSY until a batch is collected and released).
+ * One pipe per decoder thread — the reference's one-MotionScanner-per-worker model
+ * (src/pipeline.cpp:186-197); pipes of one context may be used concurrently.
+ */
+typedef struct mtgpu_pipe mtgpu_pipe;
+typedef struct mtgpu_batch mtgpu_batch;
+
+int mtgpu_pipe_create(mtgpu_ctx *ctx, uint64_t max_records_per_batch, uint32_t max_frames_per_batch,
+                      int n_buffers, mtgpu_pipe **out);
+void mtgpu_pipe_destroy(mtgpu_pipe *pipe);
+
+/* A free staging batch to fill, or MT_ERR_BUSY if all are in flight / held. */
+int mtgpu_pipe_acquire(mtgpu_pipe *pipe, mtgpu_batch **out);
+
+/* Append one decoded frame: copies n_bytes / 40 records (trailing bytes ignored, :226).
+ * mv_bytes == NULL with has_side_data == 0 records a frame without MV side data (:219-221).
+ * `tag` is carried through untouched (e.g. a frame index).  MT_ERR_CAPACITY if the frame
+ * does not fit the batch: submit this batch and add the frame to the next one. */
+int mtgpu_batch_add_frame(mtgpu_batch *batch, const void *mv_bytes, uint64_t n_bytes,
+                          int has_side_data, double pts, uint64_t tag);
+uint32_t mtgpu_batch_frames(const mtgpu_batch *batch);
+
+/* Asynchronous: H2D copy + scan + flags D2H on the batch's stream.  Empty batches are legal. */
+int mtgpu_pipe_submit(mtgpu_pipe *pipe, mtgpu_batch *batch);
+
+/* Block until the OLDEST submitted batch is done and expose its results (host pointers valid
+ * until mtgpu_pipe_release).  MT_ERR_INVALID if nothing is in flight. */
+int mtgpu_pipe_collect(mtgpu_pipe *pipe, mtgpu_batch **out, const uint8_t **flags,
+                       const double **pts, const uint64_t **tags, uint32_t *n_frames);
+int mtgpu_pipe_release(mtgpu_pipe *pipe, mtgpu_batch *batch);
+
 #ifdef __cplusplus
 }
 #endif

@@ -3,13 +3,13 @@ Vaibhav-20022002/Motion-Estimated-Video-Trimmer (MotionScanner::check_frame + th
 gap-bounded segment merge) as hand-written gfx950 HIP kernels behind the C ABI of
 include/mtgpu.h.  This package is the thin host-side mirror of the reference's
 scanner interface; the compute lives in libmtgpu.so (csrc/)."""
-from . import config
+from . import config, mvfile, mvjson
 from ._abi import (LIB_PATH, MERGE_PARAMS_DTYPE, MERGE_RESULT_DTYPE, MV_DTYPE, SEGMENT_DTYPE,
                    MtgpuError, load_library)
-from .scanner import (FrameBatch, MergeParams, MotionScanner, ScanParams, filter_frames,
+from .scanner import (FrameBatch, MergeParams, MotionScanner, ScanParams, ScanPipe, filter_frames,
                       frame_skip, make_chunks, results_from_bytes)
 
-__all__ = ["config", "LIB_PATH", "MV_DTYPE", "SEGMENT_DTYPE", "MERGE_PARAMS_DTYPE",
+__all__ = ["config", "mvfile", "mvjson", "LIB_PATH", "MV_DTYPE", "SEGMENT_DTYPE", "MERGE_PARAMS_DTYPE",
            "MERGE_RESULT_DTYPE", "MtgpuError", "load_library", "FrameBatch", "MergeParams",
-           "MotionScanner", "ScanParams", "filter_frames", "frame_skip", "make_chunks",
+           "MotionScanner", "ScanParams", "ScanPipe", "filter_frames", "frame_skip", "make_chunks",
            "results_from_bytes"]

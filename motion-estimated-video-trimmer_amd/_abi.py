@@ -13,7 +13,7 @@ import numpy as np
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "libmtgpu.so")
 
-MT_OK, MT_ERR_INVALID, MT_ERR_CAPACITY, MT_ERR_DEVICE, MT_ERR_NOMEM = 0, 1, 2, 3, 4
+MT_OK, MT_ERR_INVALID, MT_ERR_CAPACITY, MT_ERR_DEVICE, MT_ERR_NOMEM, MT_ERR_BUSY = 0, 1, 2, 3, 4, 5
 
 # AVMotionVector-compatible record (include/mt_types.h: mt_mv; 40 bytes).
 MV_DTYPE = np.dtype(
@@ -80,6 +80,15 @@ ABI = {
     "mtgpu_merge_streams_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_uint32, C.c_void_p, C.c_int, C.c_void_p,
                                              C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "mtgpu_pipe_create": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.POINTER(C.c_void_p)]),
+    "mtgpu_pipe_destroy": (None, [C.c_void_p]),
+    "mtgpu_pipe_acquire": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "mtgpu_batch_add_frame": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_double, C.c_uint64]),
+    "mtgpu_batch_frames": (C.c_uint32, [C.c_void_p]),
+    "mtgpu_pipe_submit": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mtgpu_pipe_collect": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                     C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint32)]),
+    "mtgpu_pipe_release": (C.c_int, [C.c_void_p, C.c_void_p]),
 }
 
 _lib = None

@@ -1,0 +1,21 @@
+// api_internal.h — helpers shared by the translation units that implement the C ABI
+// (mtgpu_api.hip, pipe.hip).  Internal.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mtgpu.h"
+
+namespace mtgpu {
+
+int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+int hip_fail(hipError_t e, const char *what);
+
+int ctx_device(const mtgpu_ctx *c);
+int ctx_bands(const mtgpu_ctx *c);
+// Launch the scan for a device-resident batch on `st` (d_centres: n_frames words when bands > 1).
+int ctx_launch_scan(mtgpu_ctx *c, const void *d_mv, uint64_t n_records, const uint64_t *d_off,
+                    const uint8_t *d_sd, uint32_t n_frames, uint8_t *d_flags, unsigned int *d_centres,
+                    hipStream_t st);
+
+}  // namespace mtgpu

@@ -1,0 +1,363 @@
+// mtgpu_host.hpp — C++ host layer above the C ABI (include/mtgpu.h): the re-plumbed
+// scan half of the reference's per-video pipeline.
+//
+//   reference (file:line in the reference tree)           here
+//   ------------------------------------------------      -----------------------------------
+//   Config:: getters (config.hpp:56-125)                   mtgpu_host::Config
+//   ScanTask / TaskQueue (types.hpp:92-96, task_queue.*)   ScanTask / TaskQueue
+//   ResultCollector (task_queue.cpp:43-57)                 ResultCollector
+//   MotionScanner::initialize / scan_range                 GpuMotionScanner (decode stays behind
+//     (motion_scanner.cpp:62-202, 297-391)                   the FrameSource interface)
+//   worker loop + merge of ProcessingPipeline::run         run_scan_pipeline
+//     (pipeline.cpp:130-167, 186-235, 297-358, 387-388)
+//
+// FFmpeg demux/decode is NOT here: a FrameSource hands over already-decoded frames
+// (pts + MV side-data bytes).  A libav-backed FrameSource is a dozen lines around the
+// reference's own decode loop (motion_scanner.cpp:334-354); MtmvSource below reads the
+// repo's binary MV container so the whole path runs on boxes without FFmpeg.
+#pragma once
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <condition_variable>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <queue>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include "mtgpu.h"
+
+namespace mtgpu_host {
+
+// ---------------------------------------------------------------- configuration
+struct Config {   // same variables, defaults and parse types as config.hpp:56-125
+  static double env_d(const char *n, double d) { const char *v = std::getenv(n); return v ? std::stod(v) : d; }
+  static int env_i(const char *n, int d) { const char *v = std::getenv(n); return v ? std::stoi(v) : d; }
+  static float env_f(const char *n, float d) { const char *v = std::getenv(n); return v ? std::stof(v) : d; }
+  static double mv_threshold_sq() { return env_d("MV_THRESHOLD_SQ", 16.0); }
+  static int block_size() { return env_i("BLOCK_SIZE", 16); }
+  static int block_shift() { return env_i("BLOCK_SHIFT", 4); }
+  static int vectors_needed() { return static_cast<uint8_t>(env_i("VECTORS_NEEDED", 2)); }
+  static int clusters_needed() { return env_i("CLUSTERS_NEEDED", 2); }
+  static float vertical_mask() { return env_f("VERTICAL_MASK", 0.05f); }
+  static double max_gap_sec() { return env_d("MAX_GAP_SEC", 5.0); }
+  static double padding_sec() { return env_d("PADDING_SEC", 0.5); }
+  static double chunk_duration_sec() { return env_d("CHUNK_DURATION_SEC", 30.0); }
+  static double target_fps() { return env_d("TARGET_FPS", 0.0); }
+  static double min_savings_pct() { return env_d("MIN_SAVINGS_PCT", 5.0); }
+};
+
+// ---------------------------------------------------------------- work / result plumbing
+struct ScanTask { double start, end; int id; };
+
+class TaskQueue {   // mutex + condvar FIFO of chunks, as task_queue.cpp:20-39
+  std::queue<ScanTask> q_;
+  std::mutex mu_;
+  std::condition_variable cv_;
+  bool done_ = false;
+ public:
+  void push(ScanTask t) { { std::lock_guard<std::mutex> l(mu_); q_.push(t); } cv_.notify_one(); }
+  bool pop(ScanTask &t) {
+    std::unique_lock<std::mutex> l(mu_);
+    cv_.wait(l, [&] { return !q_.empty() || done_; });
+    if (q_.empty()) return false;
+    t = q_.front(); q_.pop();
+    return true;
+  }
+  void finish() { { std::lock_guard<std::mutex> l(mu_); done_ = true; } cv_.notify_all(); }
+};
+
+class ResultCollector {   // unordered pooling of per-chunk timestamps, task_queue.cpp:43-57
+  std::vector<double> ts_;
+  std::mutex mu_;
+ public:
+  void add(std::vector<double> &&r) { std::lock_guard<std::mutex> l(mu_); ts_.insert(ts_.end(), r.begin(), r.end()); }
+  std::vector<double> extract() { std::lock_guard<std::mutex> l(mu_); return std::move(ts_); }
+};
+
+// ---------------------------------------------------------------- decoded-frame interface
+struct Frame {
+  int64_t pts = 0;             // AVFrame::pts in time_base units
+  const void *mv = nullptr;    // AV_FRAME_DATA_MOTION_VECTORS bytes, nullptr if absent
+  size_t mv_bytes = 0;
+  bool has_side_data = false;
+};
+
+class FrameSource {   // what the scan needs from a decoder (motion_scanner.cpp:204-215, 321-354)
+ public:
+  virtual ~FrameSource() = default;
+  virtual int width() const = 0;
+  virtual int height() const = 0;
+  virtual double duration() const = 0;
+  virtual double fps() const = 0;
+  virtual double time_base() const = 0;
+  // av_seek_frame(..., AVSEEK_FLAG_BACKWARD) + flush: continue from the last keyframe at or
+  // before `seconds`
+  virtual void seek(double seconds) = 0;
+  // next decoded frame in decode order; the Frame's bytes stay valid until the next call only
+  virtual bool next(Frame &f) = 0;
+};
+
+// .mtmv — the repo's binary MV container (written by mvfile.py); see that file for the layout.
+struct MtmvHeader {
+  char magic[8];
+  uint32_t width, height, tb_num, tb_den;
+  double fps, duration;
+  uint64_t n_frames, n_records;
+};
+struct MtmvFrameRec {
+  int64_t pts;
+  uint64_t rec_off;
+  uint32_t n_rec;
+  uint8_t has_sd, key, pad[2];
+};
+static_assert(sizeof(MtmvHeader) == 56 && sizeof(MtmvFrameRec) == 24, "mtmv layout");
+
+class MtmvFile {   // one mmap shared by all sources of a video (the reference mmaps the input once, memory_io.cpp:73-132)
+  int fd_ = -1;
+  const uint8_t *base_ = nullptr;
+  size_t size_ = 0;
+ public:
+  const MtmvHeader *hdr = nullptr;
+  const MtmvFrameRec *frames = nullptr;
+  const uint8_t *records = nullptr;
+  explicit MtmvFile(const std::string &path) {
+    fd_ = ::open(path.c_str(), O_RDONLY);
+    if (fd_ < 0) throw std::runtime_error("cannot open " + path);
+    struct stat st{};
+    if (fstat(fd_, &st) != 0 || st.st_size < (off_t)sizeof(MtmvHeader)) throw std::runtime_error("bad mtmv file");
+    size_ = (size_t)st.st_size;
+    base_ = static_cast<const uint8_t *>(mmap(nullptr, size_, PROT_READ, MAP_PRIVATE, fd_, 0));
+    if (base_ == MAP_FAILED) throw std::runtime_error("mmap failed");
+    hdr = reinterpret_cast<const MtmvHeader *>(base_);
+    if (std::memcmp(hdr->magic, "MTMV1\0\0\0", 8) != 0) throw std::runtime_error("not an mtmv file");
+    frames = reinterpret_cast<const MtmvFrameRec *>(base_ + sizeof(MtmvHeader));
+    records = base_ + sizeof(MtmvHeader) + sizeof(MtmvFrameRec) * hdr->n_frames;
+    if (sizeof(MtmvHeader) + sizeof(MtmvFrameRec) * hdr->n_frames + 40ull * hdr->n_records > size_)
+      throw std::runtime_error("truncated mtmv file");
+  }
+  ~MtmvFile() { if (base_ && base_ != MAP_FAILED) munmap(const_cast<uint8_t *>(base_), size_); if (fd_ >= 0) close(fd_); }
+  MtmvFile(const MtmvFile &) = delete;
+  MtmvFile &operator=(const MtmvFile &) = delete;
+};
+
+class MtmvSource : public FrameSource {
+  const MtmvFile &f_;
+  uint64_t pos_ = 0;
+ public:
+  explicit MtmvSource(const MtmvFile &f) : f_(f) {}
+  int width() const override { return (int)f_.hdr->width; }
+  int height() const override { return (int)f_.hdr->height; }
+  double duration() const override { return f_.hdr->duration; }
+  double fps() const override { return f_.hdr->fps; }
+  double time_base() const override { return (double)f_.hdr->tb_num / (double)f_.hdr->tb_den; }   // av_q2d
+  void seek(double seconds) override {
+    const int64_t target = static_cast<int64_t>(seconds / time_base());   // motion_scanner.cpp:322
+    uint64_t key = 0;
+    for (uint64_t i = 0; i < f_.hdr->n_frames && f_.frames[i].pts <= target; ++i)
+      if (f_.frames[i].key) key = i;
+    pos_ = key;
+  }
+  bool next(Frame &fr) override {
+    if (pos_ >= f_.hdr->n_frames) return false;
+    const MtmvFrameRec &r = f_.frames[pos_++];
+    fr.pts = r.pts;
+    fr.has_side_data = r.has_sd != 0;
+    fr.mv = r.has_sd ? f_.records + 40ull * r.rec_off : nullptr;
+    fr.mv_bytes = r.has_sd ? 40ull * r.n_rec : 0;
+    return true;
+  }
+};
+
+// ---------------------------------------------------------------- scanner
+class GpuMotionScanner {   // public shape of MotionScanner (motion_scanner.hpp:113-152)
+  FrameSource &src_;
+  int device_;
+  mtgpu_ctx *ctx_ = nullptr;
+  mtgpu_pipe *pipe_ = nullptr;
+  mtgpu_batch *cur_ = nullptr;
+  int inflight_ = 0;
+  std::string err_;
+
+  bool ok(int rc) { if (rc != MT_OK) { err_ = mtgpu_last_error(); return false; } return true; }
+
+  bool collect_one(std::vector<double> &ts) {
+    mtgpu_batch *b = nullptr;
+    const uint8_t *flags = nullptr;
+    const double *pts = nullptr;
+    uint32_t n = 0;
+    if (!ok(mtgpu_pipe_collect(pipe_, &b, &flags, &pts, nullptr, &n))) return false;
+    for (uint32_t i = 0; i < n; ++i)
+      if (flags[i]) ts.push_back(pts[i]);                    // :382-383
+    --inflight_;
+    return ok(mtgpu_pipe_release(pipe_, b));
+  }
+  bool submit() {
+    if (!cur_) return true;
+    if (!ok(mtgpu_pipe_submit(pipe_, cur_))) return false;
+    cur_ = nullptr;
+    ++inflight_;
+    return true;
+  }
+  bool feed(const Frame &f, double pts, std::vector<double> &ts) {
+    for (;;) {
+      if (!cur_) {
+        int rc = mtgpu_pipe_acquire(pipe_, &cur_);
+        if (rc == MT_ERR_BUSY) { if (!collect_one(ts)) return false; continue; }   // back-pressure
+        if (!ok(rc)) return false;
+      }
+      int rc = mtgpu_batch_add_frame(cur_, f.mv, f.mv_bytes, f.has_side_data ? 1 : 0, pts, 0);
+      if (rc == MT_ERR_CAPACITY) { if (!submit()) return false; continue; }
+      return ok(rc);
+    }
+  }
+
+ public:
+  GpuMotionScanner(FrameSource &src, int device) : src_(src), device_(device) {}
+  ~GpuMotionScanner() { if (pipe_) mtgpu_pipe_destroy(pipe_); if (ctx_) mtgpu_destroy(ctx_); }
+  GpuMotionScanner(const GpuMotionScanner &) = delete;
+  GpuMotionScanner &operator=(const GpuMotionScanner &) = delete;
+  const std::string &error() const { return err_; }
+  mtgpu_ctx *context() { return ctx_; }
+
+  // cfg/grid derivation of MotionScanner::initialize (motion_scanner.cpp:184-199) + device setup
+  bool initialize(uint64_t batch_records = 1u << 20, uint32_t batch_frames = 256, int n_buffers = 3) {
+    mt_scan_params p;
+    if (!ok(mtgpu_params_from_config(&p, src_.width(), src_.height(), Config::mv_threshold_sq(),
+                                     Config::block_size(), Config::block_shift(), Config::vectors_needed(),
+                                     Config::clusters_needed(), Config::vertical_mask()))) return false;
+    if (!ok(mtgpu_create(&p, device_, &ctx_))) return false;
+    return ok(mtgpu_pipe_create(ctx_, batch_records, batch_frames, n_buffers, &pipe_));
+  }
+  double get_duration() { return src_.duration(); }
+  double get_fps() { return src_.fps(); }
+
+  // MotionScanner::scan_range (motion_scanner.cpp:297-391): same filter, same timestamps;
+  // check_frame runs on the GPU, overlapped with the "decode" of the following frames.
+  std::vector<double> scan_range(double start, double end, long &seek_us, long &decode_us, long &analyze_us) {
+    using clk = std::chrono::high_resolution_clock;
+    auto us = [](clk::time_point a, clk::time_point b) {
+      return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
+    std::vector<double> ts;
+    const double time_base = src_.time_base();
+    const double video_fps = src_.fps();
+    const double target = Config::target_fps();
+    const int frame_skip = (target > 0 && target < video_fps) ? static_cast<int>(video_fps / target) : 1;   // :311-313
+    int frame_count = 0;
+    auto t0 = clk::now();
+    if (start > 0) src_.seek(start);                                     // :321-325
+    else src_.seek(0.0);
+    auto t1 = clk::now();
+    seek_us += us(t0, t1);
+    Frame f;
+    for (;;) {
+      auto d0 = clk::now();
+      const bool got = src_.next(f);
+      auto d1 = clk::now();
+      decode_us += us(d0, d1);
+      if (!got) break;
+      if (++frame_count % frame_skip != 0) continue;                     // :357
+      const double pts = f.pts * time_base;                              // :361
+      if (pts < start) continue;                                         // :364-365
+      if (pts >= end) break;                                             // :368-371
+      auto a0 = clk::now();
+      const bool fed = feed(f, pts, ts);                                 // copy-out + async scan (:376)
+      analyze_us += us(a0, clk::now());
+      if (!fed) return ts;
+    }
+    auto a0 = clk::now();
+    if (cur_ && mtgpu_batch_frames(cur_) > 0) submit();
+    while (inflight_ > 0) if (!collect_one(ts)) break;
+    analyze_us += us(a0, clk::now());
+    return ts;
+  }
+};
+
+// ---------------------------------------------------------------- per-video pipeline (scan + merge)
+struct PipelineResult {
+  std::vector<mt_segment> segments;   // what FFmpegJob::segments would carry (pipeline.cpp:366, 396)
+  mt_merge_result merge{};
+  size_t motion_frames = 0;           // pooled timestamps before sort/unique (pipeline.cpp:294-295)
+  int chunks = 0, threads = 0;
+  long seek_us = 0, decode_us = 0, analyze_us = 0;
+  std::string error;
+};
+
+// The scan + merge part of ProcessingPipeline::run: chunk the timeline, N workers (each with its
+// own source + GpuMotionScanner, worker i on device i % n_devices), pool, merge on the GPU.
+// `make_source` is called once per worker (+ once for the probe), like the per-thread
+// MotionScanner(file_buffer) of pipeline.cpp:197.
+template <class MakeSource>
+int run_scan_pipeline(MakeSource make_source, int num_threads, PipelineResult &out) {
+  std::unique_ptr<FrameSource> probe = make_source();                    // pipeline.cpp:110-120
+  const double duration = probe->duration();
+  const double chunk = Config::chunk_duration_sec();
+  int n_dev = mtgpu_device_count();
+  if (n_dev < 1) { out.error = "no GPU"; return 1; }
+  const int num_chunks = static_cast<int>(std::ceil(duration / chunk));  // :141-142
+  num_threads = std::max(1, std::min(num_threads, std::max(1, num_chunks)));   // :143
+  TaskQueue tasks;
+  ResultCollector results;
+  int chunk_id = 0;
+  for (double t = 0; t < duration; t += chunk)                           // :163-167
+    tasks.push({t, std::min(t + chunk, duration), chunk_id++});
+  std::atomic<long> seek_us{0}, decode_us{0}, analyze_us{0};
+  std::mutex err_mu;
+  std::vector<std::thread> workers;
+  mtgpu_ctx *merge_ctx = nullptr;
+  std::mutex ctx_mu;
+  std::vector<std::unique_ptr<GpuMotionScanner>> scanners(num_threads);
+  std::vector<std::unique_ptr<FrameSource>> sources(num_threads);
+  for (int i = 0; i < num_threads; ++i) {
+    workers.emplace_back([&, i] {                                        // :186-235
+      sources[i] = make_source();
+      scanners[i] = std::make_unique<GpuMotionScanner>(*sources[i], i % n_dev);
+      if (!scanners[i]->initialize()) {                                  // :198-199 (here: reported)
+        std::lock_guard<std::mutex> l(err_mu);
+        out.error = scanners[i]->error();
+        return;
+      }
+      long s = 0, d = 0, a = 0;
+      ScanTask task;
+      while (tasks.pop(task)) {                                          // :216-223
+        auto r = scanners[i]->scan_range(task.start, task.end, s, d, a);
+        if (!r.empty()) results.add(std::move(r));
+      }
+      seek_us += s; decode_us += d; analyze_us += a;
+    });
+  }
+  tasks.finish();
+  for (auto &w : workers) w.join();
+  out.chunks = chunk_id;
+  out.threads = num_threads;
+  out.seek_us = seek_us; out.decode_us = decode_us; out.analyze_us = analyze_us;
+  if (!out.error.empty()) return 1;
+  std::vector<double> timestamps = results.extract();
+  out.motion_frames = timestamps.size();
+  for (auto &s : scanners) if (s && s->context()) { merge_ctx = s->context(); break; }
+  if (!merge_ctx) { out.error = "no scanner context"; return 1; }
+  // sort + unique + merge + clamp + savings + cut decision on the device (pipeline.cpp:302-358, 387-388)
+  mt_merge_params mp{Config::max_gap_sec(), Config::padding_sec(), duration, Config::min_savings_pct()};
+  out.segments.assign(timestamps.size() + 1, mt_segment{0, 0});
+  int rc = mtgpu_merge_segments(merge_ctx, timestamps.data(), timestamps.size(), &mp, 1, out.segments.data(),
+                                out.segments.size(), &out.merge);
+  if (rc != MT_OK) { out.error = mtgpu_last_error(); return 1; }
+  out.segments.resize(out.merge.n_segments);
+  return 0;
+}
+
+}  // namespace mtgpu_host

@@ -13,12 +13,15 @@
 #include <new>
 
 #include "../../include/mtgpu.h"
+#include "api_internal.h"
 #include "merge_kernels.h"
 #include "scan_kernels.h"
 
 namespace {
-
 thread_local char g_err[512] = "";
+}
+
+namespace mtgpu {
 
 int fail(int code, const char *fmt, ...) {
   va_list ap;
@@ -31,6 +34,13 @@ int fail(int code, const char *fmt, ...) {
 int hip_fail(hipError_t e, const char *what) {
   return fail(MT_ERR_DEVICE, "%s: %s", what, hipGetErrorString(e));
 }
+
+}  // namespace mtgpu
+
+namespace {
+
+using mtgpu::fail;
+using mtgpu::hip_fail;
 
 #define HIP_TRY(expr)                                   \
   do {                                                  \
@@ -155,6 +165,19 @@ int make_plan(mtgpu_ctx *c, int lds_max, int cu_count) {
       band_rows = chunk_rows = (int)r;
     }
   }
+  // Two workgroups per CU hide each other's zero / cluster-test phases (measured +4 % on the
+  // 960x540 grid): when only the mask buffer pushes a tile over half of LDS, chunk the cluster
+  // test so that the tile fits 80 KB.
+  {
+    const size_t half = 80u * 1024u;
+    const size_t cnt_only = lds_need(band_rows, -2, k.gw, k.W, fb, nullptr);
+    if (lds_need(band_rows, chunk_rows, k.gw, k.W, fb, nullptr) > half && cnt_only + 10u * mask_row <= half) {
+      const long ch = (long)((half - cnt_only) / mask_row) - 2;
+      if (ch >= 8 && ch < chunk_rows) chunk_rows = (int)ch;
+    }
+  }
+  const int fchunk = env_int("MTGPU_FORCE_CHUNK", 0);         // experiments: smaller mask buffer
+  if (fchunk >= 1 && fchunk < chunk_rows) chunk_rows = fchunk;
   k.fb = fb;
   k.band_rows = band_rows;
   k.chunk_rows = chunk_rows;
@@ -162,9 +185,9 @@ int make_plan(mtgpu_ctx *c, int lds_max, int cu_count) {
   k.mask_rows = chunk_rows + 2;
   const size_t lds = lds_need(band_rows, chunk_rows, k.gw, k.W, fb, &k.cnt_words);
   // Workgroup size: 512 threads x 4 loads in flight per lane keep a CU's memory queue full at
-  // 4 workgroups/CU (measured +2.5 % over 256 on 1080p); tiles above 80 KB run 1 workgroup/CU
-  // and take all 16 waves.
-  int block = lds <= 80u * 1024u ? 512 : 1024;
+  // 4 workgroups/CU (measured +2.5 % over 256 on 1080p); tiles above 48 KB run 1-2
+  // workgroups/CU and take 16 waves each.
+  int block = lds <= 48u * 1024u ? 512 : 1024;
   const int fblock = env_int("MTGPU_FORCE_BLOCK", 0);
   if (fblock == 256 || fblock == 512 || fblock == 1024) block = fblock;
   c->plan.block_threads = block;
@@ -201,6 +224,16 @@ int launch_scan_on(mtgpu_ctx *c, const void *d_mv, uint64_t n_records, const uin
 }
 
 }  // namespace
+
+namespace mtgpu {
+int ctx_device(const mtgpu_ctx *c) { return c->device; }
+int ctx_bands(const mtgpu_ctx *c) { return c->k.bands; }
+int ctx_launch_scan(mtgpu_ctx *c, const void *d_mv, uint64_t n_records, const uint64_t *d_off,
+                    const uint8_t *d_sd, uint32_t n_frames, uint8_t *d_flags, unsigned int *d_centres,
+                    hipStream_t st) {
+  return launch_scan_on(c, d_mv, n_records, d_off, d_sd, n_frames, d_flags, d_centres, st);
+}
+}  // namespace mtgpu
 
 extern "C" {
 

@@ -1,0 +1,237 @@
+// pipe.hip — host dispatcher of the C ABI (include/mtgpu.h, "Host dispatcher"):
+// pinned multi-buffered staging, asynchronous H2D + scan + D2H per batch.
+// Replaces the synchronous check_frame call in the decode loop
+// (reference src/motion_scanner.cpp:375-383) and the copy-out that the MV side
+// data's lifetime (:347) forces on any batched backend.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "api_internal.h"
+
+struct mtgpu_batch {
+  // pinned host staging
+  unsigned char *h_mv = nullptr;
+  uint64_t *h_off = nullptr;
+  uint8_t *h_sd = nullptr;
+  double *h_pts = nullptr;
+  uint64_t *h_tag = nullptr;
+  uint8_t *h_flags = nullptr;
+  // device mirrors
+  unsigned char *d_mv = nullptr;
+  uint64_t *d_off = nullptr;
+  uint8_t *d_sd = nullptr;
+  uint8_t *d_flags = nullptr;
+  unsigned int *d_centres = nullptr;
+  uint64_t cap_records = 0, n_records = 0;
+  uint32_t cap_frames = 0, n_frames = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t done = nullptr;
+  int state = 0;   // 0 free, 1 filling, 2 in flight, 3 collected
+  mtgpu_pipe *owner = nullptr;
+};
+
+struct mtgpu_pipe {
+  mtgpu_ctx *ctx = nullptr;
+  std::vector<mtgpu_batch *> bufs;
+  std::deque<mtgpu_batch *> inflight;
+  std::mutex mu;
+};
+
+namespace {
+
+using mtgpu::fail;
+using mtgpu::hip_fail;
+
+void free_batch(mtgpu_batch *b) {
+  if (!b) return;
+  if (b->stream) (void)hipStreamSynchronize(b->stream);
+  if (b->h_mv) (void)hipHostFree(b->h_mv);
+  if (b->h_off) (void)hipHostFree(b->h_off);
+  if (b->h_sd) (void)hipHostFree(b->h_sd);
+  if (b->h_pts) (void)hipHostFree(b->h_pts);
+  if (b->h_tag) (void)hipHostFree(b->h_tag);
+  if (b->h_flags) (void)hipHostFree(b->h_flags);
+  if (b->d_mv) (void)hipFree(b->d_mv);
+  if (b->d_off) (void)hipFree(b->d_off);
+  if (b->d_sd) (void)hipFree(b->d_sd);
+  if (b->d_flags) (void)hipFree(b->d_flags);
+  if (b->d_centres) (void)hipFree(b->d_centres);
+  if (b->done) (void)hipEventDestroy(b->done);
+  if (b->stream) (void)hipStreamDestroy(b->stream);
+  delete b;
+}
+
+#define PIPE_TRY(expr)                                               \
+  do {                                                               \
+    hipError_t _e = (expr);                                          \
+    if (_e != hipSuccess) { rc = hip_fail(_e, #expr); goto bad; }    \
+  } while (0)
+
+int alloc_batch(mtgpu_batch **out, uint64_t max_records, uint32_t max_frames, int bands) {
+  int rc = MT_OK;
+  mtgpu_batch *b = new (std::nothrow) mtgpu_batch();
+  if (!b) return fail(MT_ERR_NOMEM, "out of host memory");
+  b->cap_records = max_records;
+  b->cap_frames = max_frames;
+  {
+    const size_t mvb = (size_t)max_records * MT_MV_BYTES + 64;
+    const size_t nf = (size_t)max_frames;
+    PIPE_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_mv), mvb, hipHostMallocDefault));
+    PIPE_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_off), sizeof(uint64_t) * (nf + 1), hipHostMallocDefault));
+    PIPE_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_sd), nf + 1, hipHostMallocDefault));
+    PIPE_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_pts), sizeof(double) * (nf + 1), hipHostMallocDefault));
+    PIPE_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_tag), sizeof(uint64_t) * (nf + 1), hipHostMallocDefault));
+    PIPE_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_flags), nf + 1, hipHostMallocDefault));
+    PIPE_TRY(hipMalloc(reinterpret_cast<void **>(&b->d_mv), mvb));
+    PIPE_TRY(hipMalloc(reinterpret_cast<void **>(&b->d_off), sizeof(uint64_t) * (nf + 1)));
+    PIPE_TRY(hipMalloc(reinterpret_cast<void **>(&b->d_sd), nf + 1));
+    PIPE_TRY(hipMalloc(reinterpret_cast<void **>(&b->d_flags), nf + 1));
+    if (bands > 1) PIPE_TRY(hipMalloc(reinterpret_cast<void **>(&b->d_centres), sizeof(unsigned int) * (nf + 1)));
+    PIPE_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    PIPE_TRY(hipEventCreateWithFlags(&b->done, hipEventDisableTiming));
+  }
+  b->h_off[0] = 0;
+  *out = b;
+  return MT_OK;
+bad:
+  free_batch(b);
+  return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mtgpu_pipe_create(mtgpu_ctx *ctx, uint64_t max_records_per_batch, uint32_t max_frames_per_batch,
+                      int n_buffers, mtgpu_pipe **out) {
+  if (!ctx || !out) return fail(MT_ERR_INVALID, "NULL argument");
+  *out = nullptr;
+  if (max_records_per_batch == 0 || max_frames_per_batch == 0 || n_buffers < 1 || n_buffers > 64)
+    return fail(MT_ERR_INVALID, "pipe needs max_records > 0, max_frames > 0, 1 <= n_buffers <= 64");
+  hipError_t e = hipSetDevice(mtgpu::ctx_device(ctx));
+  if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+  mtgpu_pipe *p = new (std::nothrow) mtgpu_pipe();
+  if (!p) return fail(MT_ERR_NOMEM, "out of host memory");
+  p->ctx = ctx;
+  for (int i = 0; i < n_buffers; ++i) {
+    mtgpu_batch *b = nullptr;
+    int rc = alloc_batch(&b, max_records_per_batch, max_frames_per_batch, mtgpu::ctx_bands(ctx));
+    if (rc != MT_OK) { mtgpu_pipe_destroy(p); return rc; }
+    b->owner = p;
+    p->bufs.push_back(b);
+  }
+  *out = p;
+  return MT_OK;
+}
+
+void mtgpu_pipe_destroy(mtgpu_pipe *p) {
+  if (!p) return;
+  (void)hipSetDevice(mtgpu::ctx_device(p->ctx));
+  for (mtgpu_batch *b : p->bufs) free_batch(b);
+  delete p;
+}
+
+int mtgpu_pipe_acquire(mtgpu_pipe *p, mtgpu_batch **out) {
+  if (!p || !out) return fail(MT_ERR_INVALID, "NULL argument");
+  std::lock_guard<std::mutex> lock(p->mu);
+  for (mtgpu_batch *b : p->bufs)
+    if (b->state == 0) {
+      b->state = 1;
+      b->n_frames = 0;
+      b->n_records = 0;
+      b->h_off[0] = 0;
+      *out = b;
+      return MT_OK;
+    }
+  *out = nullptr;
+  return fail(MT_ERR_BUSY, "all %zu staging batches are in flight or held: collect and release one", p->bufs.size());
+}
+
+int mtgpu_batch_add_frame(mtgpu_batch *b, const void *mv_bytes, uint64_t n_bytes, int has_side_data,
+                          double pts, uint64_t tag) {
+  if (!b) return fail(MT_ERR_INVALID, "batch is NULL");
+  if (b->state != 1) return fail(MT_ERR_INVALID, "batch is not being filled (acquire it first)");
+  const uint64_t n = (mv_bytes && has_side_data) ? n_bytes / MT_MV_BYTES : 0;   // :226 integer division
+  if (b->n_frames >= b->cap_frames || b->n_records + n > b->cap_records) {
+    if (b->n_frames == 0 && n > b->cap_records)
+      return fail(MT_ERR_INVALID, "a frame of %llu records exceeds the pipe's batch capacity %llu",
+                  (unsigned long long)n, (unsigned long long)b->cap_records);
+    return fail(MT_ERR_CAPACITY, "batch full");
+  }
+  if (n) std::memcpy(b->h_mv + (size_t)b->n_records * MT_MV_BYTES, mv_bytes, (size_t)n * MT_MV_BYTES);
+  const uint32_t f = b->n_frames;
+  b->n_records += n;
+  b->h_off[f + 1] = b->n_records;
+  b->h_sd[f] = has_side_data ? 1 : 0;
+  b->h_pts[f] = pts;
+  b->h_tag[f] = tag;
+  b->n_frames = f + 1;
+  return MT_OK;
+}
+
+uint32_t mtgpu_batch_frames(const mtgpu_batch *b) { return b ? b->n_frames : 0; }
+
+int mtgpu_pipe_submit(mtgpu_pipe *p, mtgpu_batch *b) {
+  if (!p || !b || b->owner != p) return fail(MT_ERR_INVALID, "batch does not belong to this pipe");
+  if (b->state != 1) return fail(MT_ERR_INVALID, "batch is not being filled");
+  hipError_t e = hipSetDevice(mtgpu::ctx_device(p->ctx));
+  if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+  hipStream_t st = b->stream;
+  if (b->n_frames) {
+    if (b->n_records) {
+      e = hipMemcpyAsync(b->d_mv, b->h_mv, (size_t)b->n_records * MT_MV_BYTES, hipMemcpyHostToDevice, st);
+      if (e != hipSuccess) return hip_fail(e, "H2D records");
+    }
+    e = hipMemcpyAsync(b->d_off, b->h_off, sizeof(uint64_t) * ((size_t)b->n_frames + 1), hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) return hip_fail(e, "H2D offsets");
+    e = hipMemcpyAsync(b->d_sd, b->h_sd, b->n_frames, hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) return hip_fail(e, "H2D has_sd");
+    int rc = mtgpu::ctx_launch_scan(p->ctx, b->d_mv, b->n_records, b->d_off, b->d_sd, b->n_frames, b->d_flags,
+                                    b->d_centres, st);
+    if (rc != MT_OK) return rc;
+    e = hipMemcpyAsync(b->h_flags, b->d_flags, b->n_frames, hipMemcpyDeviceToHost, st);
+    if (e != hipSuccess) return hip_fail(e, "D2H flags");
+  }
+  e = hipEventRecord(b->done, st);
+  if (e != hipSuccess) return hip_fail(e, "hipEventRecord");
+  std::lock_guard<std::mutex> lock(p->mu);
+  b->state = 2;
+  p->inflight.push_back(b);
+  return MT_OK;
+}
+
+int mtgpu_pipe_collect(mtgpu_pipe *p, mtgpu_batch **out, const uint8_t **flags, const double **pts,
+                       const uint64_t **tags, uint32_t *n_frames) {
+  if (!p || !out) return fail(MT_ERR_INVALID, "NULL argument");
+  mtgpu_batch *b = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(p->mu);
+    if (p->inflight.empty()) return fail(MT_ERR_INVALID, "no batch in flight");
+    b = p->inflight.front();
+    p->inflight.pop_front();
+    b->state = 3;
+  }
+  hipError_t e = hipEventSynchronize(b->done);
+  if (e != hipSuccess) return hip_fail(e, "hipEventSynchronize");
+  *out = b;
+  if (flags) *flags = b->h_flags;
+  if (pts) *pts = b->h_pts;
+  if (tags) *tags = b->h_tag;
+  if (n_frames) *n_frames = b->n_frames;
+  return MT_OK;
+}
+
+int mtgpu_pipe_release(mtgpu_pipe *p, mtgpu_batch *b) {
+  if (!p || !b || b->owner != p) return fail(MT_ERR_INVALID, "batch does not belong to this pipe");
+  std::lock_guard<std::mutex> lock(p->mu);
+  if (b->state != 3 && b->state != 1) return fail(MT_ERR_INVALID, "batch is in flight");
+  b->state = 0;
+  return MT_OK;
+}
+
+}  // extern "C"

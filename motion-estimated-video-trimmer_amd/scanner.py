@@ -286,6 +286,95 @@ class MotionScanner:
         return seg, res
 
 
+class ScanPipe:
+    """Pinned, multi-buffered host->device scan pipeline (include/mtgpu.h "Host dispatcher"):
+    what a decoder thread uses instead of calling check_frame per frame
+    (src/motion_scanner.cpp:375-383).  feed() copies a frame's MV side data into pinned
+    staging and submits full batches asynchronously; drain() returns every finished
+    (pts, flag, tag) in submission order."""
+
+    def __init__(self, scanner: MotionScanner, max_records: int, max_frames: int, n_buffers: int = 3):
+        self._lib = scanner._lib
+        self._scanner = scanner            # keeps the context alive
+        self._pipe = C.c_void_p()
+        check(self._lib.mtgpu_pipe_create(scanner._ctx, int(max_records), int(max_frames), int(n_buffers),
+                                          C.byref(self._pipe)))
+        self._cur = None
+        self._inflight = 0
+        self._done: List[Tuple[float, int, int]] = []
+
+    def close(self):
+        if getattr(self, "_pipe", None) and self._pipe.value:
+            self._lib.mtgpu_pipe_destroy(self._pipe)
+            self._pipe = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _collect_one(self):
+        b, fl, pts, tags, n = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint32()
+        check(self._lib.mtgpu_pipe_collect(self._pipe, C.byref(b), C.byref(fl), C.byref(pts), C.byref(tags),
+                                           C.byref(n)))
+        k = n.value
+        if k:
+            f = np.ctypeslib.as_array(C.cast(fl, C.POINTER(C.c_uint8)), (k,)).copy()
+            p = np.ctypeslib.as_array(C.cast(pts, C.POINTER(C.c_double)), (k,)).copy()
+            t = np.ctypeslib.as_array(C.cast(tags, C.POINTER(C.c_uint64)), (k,)).copy()
+            self._done += list(zip(p.tolist(), f.tolist(), t.tolist()))
+        check(self._lib.mtgpu_pipe_release(self._pipe, b))
+        self._inflight -= 1
+
+    def _acquire(self):
+        while True:
+            b = C.c_void_p()
+            rc = self._lib.mtgpu_pipe_acquire(self._pipe, C.byref(b))
+            if rc == _abi.MT_ERR_BUSY:          # back-pressure: finish the oldest batch first
+                self._collect_one()
+                continue
+            check(rc)
+            return b
+
+    def _submit(self):
+        if self._cur is not None:
+            check(self._lib.mtgpu_pipe_submit(self._pipe, self._cur))
+            self._cur = None
+            self._inflight += 1
+
+    def feed(self, mv: Optional[np.ndarray], pts: float, tag: int = 0):
+        """One decoded frame: `mv` is its MV side data (MV_DTYPE array or raw bytes), None when
+        the frame has no side data."""
+        if mv is None:
+            ptr, nbytes, sd = None, 0, 0
+        else:
+            a = np.ascontiguousarray(mv)
+            ptr, nbytes, sd = (a.ctypes.data_as(C.c_void_p) if a.nbytes else None), a.nbytes, 1
+        while True:
+            if self._cur is None:
+                self._cur = self._acquire()
+            rc = self._lib.mtgpu_batch_add_frame(self._cur, ptr, nbytes, sd, float(pts), int(tag))
+            if rc == _abi.MT_ERR_CAPACITY:      # batch full: ship it, start the next one
+                self._submit()
+                continue
+            check(rc)
+            return
+
+    def drain(self) -> List[Tuple[float, int, int]]:
+        """Submit the partial batch, wait for everything in flight, return and clear the
+        accumulated (pts, flag, tag) list."""
+        if self._cur is not None and self._lib.mtgpu_batch_frames(self._cur) > 0:
+            self._submit()
+        elif self._cur is not None:
+            check(self._lib.mtgpu_pipe_release(self._pipe, self._cur))
+            self._cur = None
+        while self._inflight:
+            self._collect_one()
+        out, self._done = self._done, []
+        return out
+
+
 def results_from_bytes(res_bytes: np.ndarray) -> np.ndarray:
     """uint8 [S,40] (host) -> structured mt_merge_result records."""
     return np.ascontiguousarray(res_bytes).view(MERGE_RESULT_DTYPE).reshape(-1)

@@ -15,6 +15,11 @@ import mvtrim_amd as m  # noqa: E402
 from bench import make_spec  # noqa: E402
 from mvtrim_amd import synth  # noqa: E402
 
+VARIANTS_FINE = [("default", dict()), ("chunk64", dict(MTGPU_FORCE_CHUNK="64")),
+                 ("chunk64/b1024", dict(MTGPU_FORCE_CHUNK="64", MTGPU_FORCE_BLOCK="1024")),
+                 ("chunk32/b512", dict(MTGPU_FORCE_CHUNK="32", MTGPU_FORCE_BLOCK="512")),
+                 ("chunk160/b512", dict(MTGPU_FORCE_CHUNK="160", MTGPU_FORCE_BLOCK="512")),
+                 ("fb2", dict(MTGPU_FORCE_FB="2"))]
 VARIANTS = [("fb32", dict(MTGPU_FORCE_FB="32")), ("fb2", dict(MTGPU_FORCE_FB="2")),
             ("fb32/b512", dict(MTGPU_FORCE_FB="32", MTGPU_FORCE_BLOCK="512")),
             ("fb2/b512", dict(MTGPU_FORCE_FB="2", MTGPU_FORCE_BLOCK="512")),
@@ -39,7 +44,7 @@ def main():
         if spec.sub == 1:
             kw["vectors_needed"] = 1
         params = m.ScanParams.from_config(W, H, **kw)
-        frames = FRAMES[wl]
+        frames = int(os.environ.get("AB_FRAMES", FRAMES[wl]))
         reps = (frames + distinct - 1) // distinct
         counts = np.tile(np.diff(off.astype(np.int64)), reps)[:frames]
         off_big = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
@@ -47,8 +52,8 @@ def main():
         d_off = torch.from_numpy(off_big).to(dev)
         alg = 40 * int(off_big[-1]) + 9 * frames
         scanners = []
-        for name, env in VARIANTS:
-            for k in ("MTGPU_FORCE_FB", "MTGPU_FORCE_BLOCK"):
+        for name, env in (VARIANTS_FINE if os.environ.get("AB_SET") == "fine" else VARIANTS):
+            for k in ("MTGPU_FORCE_FB", "MTGPU_FORCE_BLOCK", "MTGPU_FORCE_CHUNK"):
                 os.environ.pop(k, None)
             os.environ.update(env)
             try:
