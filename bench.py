@@ -118,10 +118,19 @@ def main():
 
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps)]
-    gathered = None
+    # two sets of merge outputs / gather buffers: the gather of step i overlaps the scan of step i+1
+    packed_w = SEG_CAP * 16 + m.MERGE_RESULT_DTYPE.itemsize
+    outs = [(torch.zeros((S, SEG_CAP, 2), dtype=torch.float64, device=dev),
+             torch.zeros((S, m.MERGE_RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev),
+             torch.empty(2 * a.frames, dtype=torch.float64, device=dev)) for _ in range(2)]
+    gath = [torch.empty((world, S, packed_w), dtype=torch.uint8, device=dev if a.backend == "nccl" else "cpu")
+            for _ in range(2)] if world > 1 else None
+    pending = [None, None]
+    counter = [0]
 
     def step(i=None):
-        nonlocal gathered
+        k = counter[0] & 1
+        counter[0] += 1
         if i is not None:
             ev0[i].record()
         scanner.check_frames_device(d_mv, d_off, None, d_flags)
@@ -129,17 +138,29 @@ def main():
             ev1[i].record()
         if a.no_merge:
             return None
-        seg, res = scanner.merge_streams_device(d_flags, d_pts, d_soff, d_mp, True, SEG_CAP)
+        if pending[k] is not None:          # buffer set k is still being gathered (two steps ago)
+            pending[k].wait()
+            pending[k] = None
+        seg, res = scanner.merge_streams_device(d_flags, d_pts, d_soff, d_mp, True, SEG_CAP, out=outs[k])
         if world > 1:
-            # the only exchange step of the path: per-GPU segment lists to every rank (RCCL over xGMI)
+            # the only exchange step of the path: per-GPU segment lists to every rank (RCCL over xGMI),
+            # asynchronous so that it overlaps the next step's scan
+            packed = mdist.pack_segment_lists(seg, res)
             if a.backend == "nccl":
-                gathered = mdist.gather_segment_lists(seg, res, out=gathered)
+                pending[k] = dist.all_gather_into_tensor(gath[k], packed, async_op=True)
             else:       # rehearsal only: gloo moves the lists through host memory
-                gathered = mdist.gather_segment_lists(seg.cpu(), res.cpu(), out=gathered)
+                mdist.gather_segment_lists(seg.cpu(), res.cpu(), out=gath[k])
         return seg, res
+
+    def finish():
+        for k in (0, 1):
+            if pending[k] is not None:
+                pending[k].wait()
+                pending[k] = None
 
     for _ in range(a.warmup):
         step()
+    finish()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -148,6 +169,7 @@ def main():
     out = None
     for i in range(a.steps):
         out = step(i)
+    finish()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -73,6 +73,7 @@ struct mtgpu_ctx {
   mtgpu_plan plan;
   int device;
   hipStream_t stream;    // private stream of the host-pointer entry points
+  int variant = 0;       // MTGPU_VARIANT experiment knob
   std::mutex mu;         // guards the staging buffers below
   DevBuf d_mv, d_off, d_sd, d_flags, d_misc;
 };
@@ -198,6 +199,7 @@ int make_plan(mtgpu_ctx *c, int lds_max, int cu_count) {
   c->plan.device = c->device;
   c->plan.cu_count = cu_count;
   c->plan.chunk_rows = chunk_rows;
+  c->variant = env_int("MTGPU_VARIANT", 0);
   c->plan.counter_mode = mode;
   c->plan._pad = 0;
   return MT_OK;
@@ -216,6 +218,7 @@ int launch_scan_on(mtgpu_ctx *c, const void *d_mv, uint64_t n_records, const uin
   L.frame_centres = d_centres;
   L.k = c->k;
   L.block = c->plan.block_threads;
+  L.variant = c->variant;
   L.lds_bytes = c->plan.lds_bytes;
   L.stream = st;
   hipError_t e = mtgpu::launch_scan(L);

@@ -36,6 +36,7 @@ struct ScanLaunch {
   unsigned int *frame_centres;  // n_frames words, only when k.bands > 1
   ScanK k;
   int block;
+  int variant;             // experiment knob (MTGPU_VARIANT), 0 = shipped kernel
   int lds_bytes;
   hipStream_t stream;
 };

@@ -43,8 +43,21 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // Bytes 4..15 of a record: d.x = w | h<<8 | src_x<<16, d.y = src_y | dst_x<<16,
 // d.z = dst_y | pad<<16   (layout: include/mt_types.h, mt_mv).
+typedef u32x4 u32x4_a8 __attribute__((aligned(8)));
+
+// VAR bit1: 16-byte load of bytes 0..15 instead of 12 bytes at +4; bit2: default cache policy
+// instead of the streaming (nt) hint.  Experiment knobs (MTGPU_VARIANT), results in DESIGN.md.
+template <int VAR>
 __device__ __forceinline__ u32x3 load_fields(const unsigned char *rec) {
-  return __builtin_nontemporal_load(reinterpret_cast<const u32x3_a4 *>(rec + 4));
+  if constexpr ((VAR & 2) != 0) {
+    u32x4 q;
+    if constexpr ((VAR & 4) != 0) q = *reinterpret_cast<const u32x4_a8 *>(rec);
+    else q = __builtin_nontemporal_load(reinterpret_cast<const u32x4_a8 *>(rec));
+    return (u32x3){q.y, q.z, q.w};
+  } else {
+    if constexpr ((VAR & 4) != 0) return *reinterpret_cast<const u32x3_a4 *>(rec + 4);
+    else return __builtin_nontemporal_load(reinterpret_cast<const u32x3_a4 *>(rec + 4));
+  }
 }
 
 enum { MODE_ADD32 = 0, MODE_UNARY = 1, MODE_CAS = 2 };
@@ -108,7 +121,7 @@ __device__ __forceinline__ void vote(const u32x3 d, const ScanK &k, int t0, int 
   if (in) bump<FB, MODE>(cnt, (unsigned int)((gy - t0) * k.gw + gx), k.vec_need);
 }
 
-template <int BLOCK, int UNROLL, int FB, int MODE>
+template <int BLOCK, int UNROLL, int FB, int MODE, int VAR>
 __global__ __launch_bounds__(BLOCK) void scan_frames_kernel(
     const unsigned char *__restrict__ mv, unsigned long long n_records,
     const unsigned long long *__restrict__ frame_off, const unsigned char *__restrict__ has_sd,
@@ -156,15 +169,43 @@ __global__ __launch_bounds__(BLOCK) void scan_frames_kernel(
     const unsigned char *base = mv + r0 * 40ull;
     const unsigned long long n = r1 - r0;
     unsigned long long i = tid;
-    // main body: UNROLL independent loads in flight per lane
-    for (; i + (unsigned long long)(UNROLL - 1) * BLOCK < n; i += (unsigned long long)UNROLL * BLOCK) {
-      u32x3 d[UNROLL];
+    constexpr unsigned long long STEP = (unsigned long long)UNROLL * BLOCK;
+    constexpr unsigned long long LAST = (unsigned long long)(UNROLL - 1) * BLOCK;
+    if constexpr ((VAR & 8) != 0) {
+      // software-pipelined: the next batch of loads is issued before this batch is consumed
+      u32x3 cur[UNROLL], nxt[UNROLL];
+      bool have = i + LAST < n;
+      if (have) {
 #pragma unroll
-      for (int u = 0; u < UNROLL; ++u) d[u] = load_fields(base + (i + (unsigned long long)u * BLOCK) * 40ull);
+        for (int u = 0; u < UNROLL; ++u) cur[u] = load_fields<VAR>(base + (i + (unsigned long long)u * BLOCK) * 40ull);
+      }
+      while (have) {
+        const unsigned long long j = i + STEP;
+        const bool more = j + LAST < n;
+        if (more) {
 #pragma unroll
-      for (int u = 0; u < UNROLL; ++u) vote<FB, MODE>(d[u], k, t0, t1, cnt);
+          for (int u = 0; u < UNROLL; ++u) nxt[u] = load_fields<VAR>(base + (j + (unsigned long long)u * BLOCK) * 40ull);
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) vote<FB, MODE>(cur[u], k, t0, t1, cnt);
+        if (more) {
+#pragma unroll
+          for (int u = 0; u < UNROLL; ++u) cur[u] = nxt[u];
+        }
+        i = j;
+        have = more;
+      }
+    } else {
+      // main body: UNROLL independent loads in flight per lane
+      for (; i + LAST < n; i += STEP) {
+        u32x3 d[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) d[u] = load_fields<VAR>(base + (i + (unsigned long long)u * BLOCK) * 40ull);
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) vote<FB, MODE>(d[u], k, t0, t1, cnt);
+      }
     }
-    for (; i < n; i += BLOCK) vote<FB, MODE>(load_fields(base + i * 40ull), k, t0, t1, cnt);
+    for (; i < n; i += BLOCK) vote<FB, MODE>(load_fields<VAR>(base + i * 40ull), k, t0, t1, cnt);
   }
   __syncthreads();
 
@@ -239,9 +280,9 @@ __global__ void finalize_flags_kernel(const unsigned long long *__restrict__ fra
 
 // ------------------------------------------------------------------ launchers
 
-template <int BLOCK, int FB, int MODE>
+template <int BLOCK, int FB, int MODE, int UNROLL = 4, int VAR = 0>
 static hipError_t launch_one(const ScanLaunch &L) {
-  auto kern = scan_frames_kernel<BLOCK, 4, FB, MODE>;
+  auto kern = scan_frames_kernel<BLOCK, UNROLL, FB, MODE, VAR>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, L.lds_bytes);
   if (e != hipSuccess) return e;
@@ -257,9 +298,24 @@ static hipError_t launch_one(const ScanLaunch &L) {
   return hipSuccess;
 }
 
+// Experiment variants of the ADD32 kernel (MTGPU_VARIANT): bit0 UNROLL 8, bit1 dwordx4 loads,
+// bit2 no nt hint, bit3 software-pipelined loop.
+template <int BLOCK>
+static hipError_t launch_variant(const ScanLaunch &L) {
+  switch (L.variant & 15) {
+#define MT_VARIANT_CASE(v) case v: return launch_one<BLOCK, 32, MODE_ADD32, ((v) & 1) ? 8 : 4, (v)>(L);
+    MT_VARIANT_CASE(1) MT_VARIANT_CASE(2) MT_VARIANT_CASE(3) MT_VARIANT_CASE(4) MT_VARIANT_CASE(5)
+    MT_VARIANT_CASE(6) MT_VARIANT_CASE(7) MT_VARIANT_CASE(8) MT_VARIANT_CASE(9) MT_VARIANT_CASE(10)
+    MT_VARIANT_CASE(11) MT_VARIANT_CASE(12) MT_VARIANT_CASE(13) MT_VARIANT_CASE(14) MT_VARIANT_CASE(15)
+#undef MT_VARIANT_CASE
+    default: return launch_one<BLOCK, 32, MODE_ADD32>(L);
+  }
+}
+
 template <int BLOCK>
 static hipError_t launch_block(const ScanLaunch &L) {
   const int key = L.k.mode * 100 + L.k.fb;
+  if (key == MODE_ADD32 * 100 + 32 && (L.variant & 15) != 0 && BLOCK != 1024) return launch_variant<BLOCK>(L);
   switch (key) {
     case MODE_ADD32 * 100 + 32: return launch_one<BLOCK, 32, MODE_ADD32>(L);
     case MODE_UNARY * 100 + 1: return launch_one<BLOCK, 1, MODE_UNARY>(L);

@@ -263,18 +263,25 @@ class MotionScanner:
         return seg[:res.n_segments].copy(), out
 
     def merge_streams_device(self, flags, pts, stream_off, merge_params, job_semantics=False,
-                             seg_cap=64, stream=None):
+                             seg_cap=64, stream=None, out=None):
         """Per-stream timestamp pooling + merge without leaving the device.
         flags uint8 [F], pts float64 [F], stream_off int64 [S+1], merge_params: uint8 view of
         S mt_merge_params records (torch tensors on the scanner's device).
-        Returns (segments float64 [S, seg_cap, 2], results uint8 [S, 40])."""
+        Returns (segments float64 [S, seg_cap, 2], results uint8 [S, 40]).
+        `out` = (segments, results, workspace float64 [2F]) reuses caller buffers (no allocation,
+        no zero fill: entries past n_segments are then unspecified)."""
         import torch
         dev = pts.device
         n_streams = stream_off.numel() - 1
         n_frames = pts.numel()
-        ws = torch.empty(2 * max(n_frames, 1), dtype=torch.float64, device=dev)
-        seg = torch.zeros((max(n_streams, 0), seg_cap, 2), dtype=torch.float64, device=dev)
-        res = torch.zeros((max(n_streams, 0), MERGE_RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+        if out is not None:
+            seg, res, ws = out
+            assert seg.is_contiguous() and res.is_contiguous() and ws.numel() >= 2 * n_frames
+            assert tuple(seg.shape) == (n_streams, seg_cap, 2) and res.shape[0] == n_streams
+        else:
+            ws = torch.empty(2 * max(n_frames, 1), dtype=torch.float64, device=dev)
+            seg = torch.zeros((max(n_streams, 0), seg_cap, 2), dtype=torch.float64, device=dev)
+            res = torch.zeros((max(n_streams, 0), MERGE_RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
         if n_streams <= 0:
             return seg, res
         st = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream

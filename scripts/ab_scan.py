@@ -20,6 +20,7 @@ VARIANTS_FINE = [("default", dict()), ("chunk64", dict(MTGPU_FORCE_CHUNK="64")),
                  ("chunk32/b512", dict(MTGPU_FORCE_CHUNK="32", MTGPU_FORCE_BLOCK="512")),
                  ("chunk160/b512", dict(MTGPU_FORCE_CHUNK="160", MTGPU_FORCE_BLOCK="512")),
                  ("fb2", dict(MTGPU_FORCE_FB="2"))]
+VARIANTS_KERNEL = [("v%d" % v, dict(MTGPU_VARIANT=str(v))) for v in (0, 1, 2, 4, 8, 9, 10, 12, 3, 11, 6, 14)]
 VARIANTS = [("fb32", dict(MTGPU_FORCE_FB="32")), ("fb2", dict(MTGPU_FORCE_FB="2")),
             ("fb32/b512", dict(MTGPU_FORCE_FB="32", MTGPU_FORCE_BLOCK="512")),
             ("fb2/b512", dict(MTGPU_FORCE_FB="2", MTGPU_FORCE_BLOCK="512")),
@@ -52,8 +53,9 @@ def main():
         d_off = torch.from_numpy(off_big).to(dev)
         alg = 40 * int(off_big[-1]) + 9 * frames
         scanners = []
-        for name, env in (VARIANTS_FINE if os.environ.get("AB_SET") == "fine" else VARIANTS):
-            for k in ("MTGPU_FORCE_FB", "MTGPU_FORCE_BLOCK", "MTGPU_FORCE_CHUNK"):
+        vset = {"fine": VARIANTS_FINE, "kernel": VARIANTS_KERNEL}.get(os.environ.get("AB_SET"), VARIANTS)
+        for name, env in vset:
+            for k in ("MTGPU_FORCE_FB", "MTGPU_FORCE_BLOCK", "MTGPU_FORCE_CHUNK", "MTGPU_VARIANT"):
                 os.environ.pop(k, None)
             os.environ.update(env)
             try:
