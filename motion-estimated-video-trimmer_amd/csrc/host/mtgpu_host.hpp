@@ -302,7 +302,7 @@ struct PipelineResult {
 // `make_source` is called once per worker (+ once for the probe), like the per-thread
 // MotionScanner(file_buffer) of pipeline.cpp:197.
 template <class MakeSource>
-int run_scan_pipeline(MakeSource make_source, int num_threads, PipelineResult &out) {
+int run_scan_pipeline(MakeSource make_source, int num_threads, PipelineResult &out, int device_base = 0) {
   std::unique_ptr<FrameSource> probe = make_source();                    // pipeline.cpp:110-120
   const double duration = probe->duration();
   const double chunk = Config::chunk_duration_sec();
@@ -325,7 +325,7 @@ int run_scan_pipeline(MakeSource make_source, int num_threads, PipelineResult &o
   for (int i = 0; i < num_threads; ++i) {
     workers.emplace_back([&, i] {                                        // :186-235
       sources[i] = make_source();
-      scanners[i] = std::make_unique<GpuMotionScanner>(*sources[i], i % n_dev);
+      scanners[i] = std::make_unique<GpuMotionScanner>(*sources[i], (device_base + i) % n_dev);
       if (!scanners[i]->initialize()) {                                  // :198-199 (here: reported)
         std::lock_guard<std::mutex> l(err_mu);
         out.error = scanners[i]->error();
@@ -358,6 +358,81 @@ int run_scan_pipeline(MakeSource make_source, int num_threads, PipelineResult &o
   if (rc != MT_OK) { out.error = mtgpu_last_error(); return 1; }
   out.segments.resize(out.merge.n_segments);
   return 0;
+}
+
+// ---------------------------------------------------------------- batch of videos
+// What the reference pushes to its FFmpeg consumer (ffmpeg_queue.hpp:32-38), minus the CPU set:
+// the untouched cut executor consumes `segments` as they are.
+struct ScanJob {
+  int stream_id = -1;
+  std::string input_path, output_path;
+  std::vector<mt_segment> segments;
+  PipelineResult result;
+};
+
+class JobQueue {   // producer/consumer queue of finished scans, as ffmpeg_queue.cpp:10-34
+  std::queue<ScanJob> q_;
+  std::mutex mu_;
+  std::condition_variable cv_;
+  bool done_ = false;
+ public:
+  void push(ScanJob &&j) { { std::lock_guard<std::mutex> l(mu_); q_.push(std::move(j)); } cv_.notify_one(); }
+  bool pop(ScanJob &j) {
+    std::unique_lock<std::mutex> l(mu_);
+    cv_.wait(l, [&] { return !q_.empty() || done_; });
+    if (q_.empty()) return false;
+    j = std::move(q_.front()); q_.pop();
+    return true;
+  }
+  void finish() { { std::lock_guard<std::mutex> l(mu_); done_ = true; } cv_.notify_all(); }
+};
+
+// BatchProcessor's stream fan-out (batch_processor.cpp:81-157, 307-350) with GPUs in place of
+// CPU sets: S stream threads pull files from one queue; the workers of stream s use devices
+// (s * threads_per_stream + i) % n_devices, so concurrent streams spread over the node's GPUs.
+// Every finished scan is pushed to `jobs` (no motion -> no job, as pipeline.cpp:308-319).
+// open_source(path) must return a factory of per-worker FrameSources for that file.
+template <class OpenSource>
+int process_batch(const std::vector<std::string> &files, const std::string &output_dir, int parallel_streams,
+                  int threads_per_stream, OpenSource open_source, JobQueue &jobs, std::vector<std::string> *errors) {
+  parallel_streams = std::max(1, std::min<int>(parallel_streams, (int)files.size()));
+  threads_per_stream = std::max(1, threads_per_stream);
+  std::mutex q_mu, e_mu;
+  size_t next = 0;
+  std::atomic<int> failed{0};
+  std::vector<std::thread> streams;
+  for (int s = 0; s < parallel_streams; ++s) {
+    streams.emplace_back([&, s] {
+      for (;;) {
+        size_t idx;
+        { std::lock_guard<std::mutex> l(q_mu); if (next >= files.size()) return; idx = next++; }   // get_next_file
+        const std::string &in = files[idx];
+        ScanJob job;
+        job.stream_id = s;
+        job.input_path = in;
+        const size_t slash = in.find_last_of('/');
+        job.output_path = output_dir + "/" + (slash == std::string::npos ? in : in.substr(slash + 1));
+        int rc = 1;
+        try {
+          auto factory = open_source(in);
+          rc = run_scan_pipeline(factory, threads_per_stream, job.result, s * threads_per_stream);
+        } catch (const std::exception &e) {
+          job.result.error = e.what();
+        }
+        if (rc != 0) {
+          ++failed;
+          if (errors) { std::lock_guard<std::mutex> l(e_mu); errors->push_back(in + ": " + job.result.error); }
+          continue;
+        }
+        if (job.result.merge.do_cut < 0) continue;           // "No motion found": nothing to cut
+        job.segments = job.result.segments;
+        jobs.push(std::move(job));
+      }
+    });
+  }
+  for (auto &t : streams) t.join();
+  jobs.finish();
+  return failed.load();
 }
 
 }  // namespace mtgpu_host

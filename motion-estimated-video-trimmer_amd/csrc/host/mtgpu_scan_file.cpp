@@ -1,43 +1,75 @@
-// mtgpu_scan_file — the scan + merge half of `motion_trim <in> <out>` on the GPU, reading
-// extracted motion vectors from a .mtmv container instead of decoding with FFmpeg:
-//   mtgpu_scan_file stream.mtmv [--threads N]
-// Configuration comes from the same environment variables as the reference
-// (MV_THRESHOLD_SQ, VECTORS_NEEDED, CHUNK_DURATION_SEC, TARGET_FPS, ...).  Prints one JSON
-// object: the FFmpegJob segment list (%.17g doubles) and the merge result.
+// mtgpu_scan_file — the scan + merge half of `motion_trim` on the GPU, reading extracted motion
+// vectors from .mtmv containers instead of decoding with FFmpeg:
+//   mtgpu_scan_file stream.mtmv [more.mtmv ...] [--threads T] [--streams S] [--outdir DIR]
+// One file: like `motion_trim in out` (single ProcessingPipeline).  Several files: like
+// `motion_trim in_dir out_dir` (BatchProcessor): S streams x T workers, jobs consumed by one
+// thread (here: printed).  Configuration comes from the same environment variables as the
+// reference (MV_THRESHOLD_SQ, VECTORS_NEEDED, CHUNK_DURATION_SEC, TARGET_FPS, ...).
+// Prints one JSON object per input with a job: the FFmpegJob segment list (%.17g) + merge result.
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <string>
+#include <vector>
 
 #include "mtgpu_host.hpp"
 
+using namespace mtgpu_host;
+
+static void print_job(const std::string &input, const PipelineResult &r, const std::vector<mt_segment> &segs) {
+  std::printf("{\"input\": \"%s\", \"chunks\": %d, \"threads\": %d, \"motion_frames\": %zu, \"n_timestamps\": %llu, "
+              "\"do_cut\": %d, \"time_removed\": %.17g, \"saved_pct\": %.17g, \"seek_us\": %ld, "
+              "\"decode_us\": %ld, \"analyze_us\": %ld, \"segments\": [",
+              input.c_str(), r.chunks, r.threads, r.motion_frames, (unsigned long long)r.merge.n_timestamps,
+              r.merge.do_cut, r.merge.time_removed, r.merge.saved_pct, r.seek_us, r.decode_us, r.analyze_us);
+  for (size_t i = 0; i < segs.size(); ++i)
+    std::printf("%s[%.17g, %.17g]", i ? ", " : "", segs[i].start, segs[i].end);
+  std::printf("]}\n");
+  std::fflush(stdout);
+}
+
 int main(int argc, char **argv) {
-  if (argc < 2) {
-    std::fprintf(stderr, "usage: %s stream.mtmv [--threads N]\n", argv[0]);
+  std::vector<std::string> files;
+  int threads = 4, streams = 2;
+  std::string outdir = ".";
+  for (int i = 1; i < argc; ++i) {
+    if (!std::strcmp(argv[i], "--threads") && i + 1 < argc) threads = std::atoi(argv[++i]);
+    else if (!std::strcmp(argv[i], "--streams") && i + 1 < argc) streams = std::atoi(argv[++i]);
+    else if (!std::strcmp(argv[i], "--outdir") && i + 1 < argc) outdir = argv[++i];
+    else files.push_back(argv[i]);
+  }
+  if (files.empty()) {
+    std::fprintf(stderr, "usage: %s stream.mtmv [more.mtmv ...] [--threads T] [--streams S] [--outdir DIR]\n", argv[0]);
     return 2;
   }
-  int threads = 4;
-  for (int i = 2; i + 1 < argc; ++i)
-    if (!std::strcmp(argv[i], "--threads")) threads = std::atoi(argv[i + 1]);
   try {
-    mtgpu_host::MtmvFile file(argv[1]);
-    mtgpu_host::PipelineResult r;
-    int rc = mtgpu_host::run_scan_pipeline(
-        [&] { return std::unique_ptr<mtgpu_host::FrameSource>(new mtgpu_host::MtmvSource(file)); }, threads, r);
-    if (rc != 0) {
-      std::fprintf(stderr, "error: %s\n", r.error.c_str());
-      return 1;
+    if (files.size() == 1) {
+      MtmvFile file(files[0]);
+      PipelineResult r;
+      int rc = run_scan_pipeline([&] { return std::unique_ptr<FrameSource>(new MtmvSource(file)); }, threads, r);
+      if (rc != 0) { std::fprintf(stderr, "error: %s\n", r.error.c_str()); return 1; }
+      print_job(files[0], r, r.segments);
+      return 0;
     }
-    std::printf("{\"chunks\": %d, \"threads\": %d, \"motion_frames\": %zu, \"n_timestamps\": %llu, "
-                "\"do_cut\": %d, \"time_removed\": %.17g, \"saved_pct\": %.17g, \"seek_us\": %ld, "
-                "\"decode_us\": %ld, \"analyze_us\": %ld, \"segments\": [",
-                r.chunks, r.threads, r.motion_frames, (unsigned long long)r.merge.n_timestamps, r.merge.do_cut,
-                r.merge.time_removed, r.merge.saved_pct, r.seek_us, r.decode_us, r.analyze_us);
-    for (size_t i = 0; i < r.segments.size(); ++i)
-      std::printf("%s[%.17g, %.17g]", i ? ", " : "", r.segments[i].start, r.segments[i].end);
-    std::printf("]}\n");
+    // batch: mmaps are shared by the workers of a stream and kept until the end
+    std::mutex mm;
+    std::map<std::string, std::shared_ptr<MtmvFile>> open_files;
+    auto open_source = [&](const std::string &path) {
+      std::shared_ptr<MtmvFile> f;
+      { std::lock_guard<std::mutex> l(mm); f = open_files[path] = std::make_shared<MtmvFile>(path); }
+      return [f] { return std::unique_ptr<FrameSource>(new MtmvSource(*f)); };
+    };
+    JobQueue jobs;
+    std::vector<std::string> errors;
+    int failed = 0;
+    std::thread producer([&] { failed = process_batch(files, outdir, streams, threads, open_source, jobs, &errors); });
+    ScanJob job;                                   // the single consumer (batch_processor.cpp:138-150)
+    while (jobs.pop(job)) print_job(job.input_path, job.result, job.segments);
+    producer.join();
+    for (auto &e : errors) std::fprintf(stderr, "error: %s\n", e.c_str());
+    return failed ? 1 : 0;
   } catch (const std::exception &e) {
     std::fprintf(stderr, "error: %s\n", e.what());
     return 1;
   }
-  return 0;
 }

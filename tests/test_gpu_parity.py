@@ -436,49 +436,86 @@ def test_scan_pipe_matches_oracle(gpu_scanner_factory):
         pipe.feed(frames[1], 0.0)
 
 
-def test_cpp_host_pipeline_scan_file(tmp_path):
-    """The C++ host layer (csrc/host/mtgpu_host.hpp: TaskQueue, ResultCollector,
-    GpuMotionScanner::scan_range, run_scan_pipeline) through its front end mtgpu_scan_file on an
-    .mtmv stream, against a Python transcription of the reference's worker loop driven by the
-    oracle (chunks -> backward seek -> frame filter -> check_frame -> pool -> merge)."""
-    import json
-    import os
-    import subprocess
-    exe = os.path.join(os.path.dirname(m.LIB_PATH), "mtgpu_scan_file")
-    assert os.path.exists(exe), "build it with make -C motion-estimated-video-trimmer_amd/csrc"
-    spec = synth.StreamSpec(width=640, height=480, block=16, sub=1, fps=30.0, gop=15, seed=5)
-    n = 900                                                       # 30 s
-    spec.events = synth.scripted_events(spec, n)
-    frames = [synth.gen_frame(spec, i) for i in range(n)]
-    ticks = [spec.pts_ticks(i) for i in range(n)]
-    duration = n / spec.fps
-    path = str(tmp_path / "s.mtmv")
-    m.mvfile.write_mtmv(path, 640, 480, 1, spec.tb_den, spec.fps, duration, ticks, frames)
-    env_cfg = dict(VECTORS_NEEDED="1", CHUNK_DURATION_SEC="4", TARGET_FPS="10", MAX_GAP_SEC="2.0",
-                   PADDING_SEC="0.5", MIN_SAVINGS_PCT="5")
-    p = ob.params_from_config(640, 480, vectors_needed=1)
+def _reference_worker_loop(spec, frames, ticks, duration, p, chunk_sec, target_fps, mp):
+    """Python transcription of the reference's worker loop + merge, driven by the oracle:
+    chunks -> backward seek to a keyframe -> frame filter -> check_frame -> pool -> merge."""
     tb = 1.0 / spec.tb_den
-    skip = m.frame_skip(spec.fps, 10.0)
+    skip = m.frame_skip(spec.fps, target_fps)
     pooled = []
     keys = [i for i, f in enumerate(frames) if f is None]
-    for (c0, c1, _) in m.make_chunks(duration, 4.0):
+    for (c0, c1, _) in m.make_chunks(duration, chunk_sec):
         target = int(c0 / tb)                                     # motion_scanner.cpp:322
         first = max([k for k in keys if ticks[k] <= target] or [0])
         idx, pts = ob.filter_frames(ticks[first:], tb, c0, c1, skip)
         bt = m.FrameBatch.from_frames([frames[first + i] for i in idx])
         fl = ob.scan_frames(p, bt.mv, bt.frame_off, bt.has_sd)
         pooled += [t for t, f in zip(pts, fl) if f]
-    mp = m.MergeParams(duration=duration, max_gap_sec=2.0, padding_sec=0.5, min_savings_pct=5.0)
-    want_seg, want_res = ob.pool_and_merge(pooled, mp, True)
+    return pooled, ob.pool_and_merge(pooled, mp, True)
+
+
+def _check_job(r, pooled, want_seg, want_res):
+    assert r["motion_frames"] == len(pooled)
+    assert r["n_timestamps"] == want_res["n_timestamps"] and r["do_cut"] == want_res["do_cut"]
+    assert [[float(a).hex(), float(b).hex()] for a, b in r["segments"]] == \
+        [[float(a).hex(), float(b).hex()] for a, b in want_seg.tolist()]
+    assert float(r["time_removed"]).hex() == float(want_res["time_removed"]).hex()
+    assert float(r["saved_pct"]).hex() == float(want_res["saved_pct"]).hex()
+
+
+def _make_stream_file(tmp_path, name, seed, n, still=False):
+    spec = synth.StreamSpec(width=640, height=480, block=16, sub=1, fps=30.0, gop=15, seed=seed,
+                            salt_p=0.0 if still else 1e-3)
+    spec.events = [] if still else synth.scripted_events(spec, n)
+    frames = [synth.gen_frame(spec, i) for i in range(n)]
+    ticks = [spec.pts_ticks(i) for i in range(n)]
+    path = str(tmp_path / name)
+    m.mvfile.write_mtmv(path, 640, 480, 1, spec.tb_den, spec.fps, n / spec.fps, ticks, frames)
+    return spec, frames, ticks, path
+
+
+def test_cpp_host_pipeline_scan_file(tmp_path):
+    """The C++ host layer (csrc/host/mtgpu_host.hpp: TaskQueue, ResultCollector,
+    GpuMotionScanner::scan_range, run_scan_pipeline, process_batch) through its front end
+    mtgpu_scan_file on .mtmv streams, against a Python transcription of the reference's worker
+    loop driven by the oracle."""
+    import json
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(m.LIB_PATH), "mtgpu_scan_file")
+    assert os.path.exists(exe), "build it with make -C motion-estimated-video-trimmer_amd/csrc"
+    env_cfg = dict(VECTORS_NEEDED="1", CHUNK_DURATION_SEC="4", TARGET_FPS="10", MAX_GAP_SEC="2.0",
+                   PADDING_SEC="0.5", MIN_SAVINGS_PCT="5")
+    env = dict(os.environ, **env_cfg)
+    p = ob.params_from_config(640, 480, vectors_needed=1)
+
+    # ---- one video: ProcessingPipeline-shaped run, any worker count gives the same job
+    n = 900                                                       # 30 s
+    spec, frames, ticks, path = _make_stream_file(tmp_path, "s.mtmv", 5, n)
+    mp = m.MergeParams(duration=n / spec.fps, max_gap_sec=2.0, padding_sec=0.5, min_savings_pct=5.0)
+    pooled, (want_seg, want_res) = _reference_worker_loop(spec, frames, ticks, n / spec.fps, p, 4.0, 10.0, mp)
     assert len(want_seg) >= 2
     for threads in (1, 3, 8):
-        env = dict(os.environ, **env_cfg)
         out = subprocess.run([exe, path, "--threads", str(threads)], check=True, capture_output=True,
                              text=True, env=env).stdout
         r = json.loads(out)
-        assert r["chunks"] == 8 and r["motion_frames"] == len(pooled)
-        assert r["n_timestamps"] == want_res["n_timestamps"] and r["do_cut"] == want_res["do_cut"]
-        assert [[float(a).hex(), float(b).hex()] for a, b in r["segments"]] == \
-            [[float(a).hex(), float(b).hex()] for a, b in want_seg.tolist()]
-        assert float(r["time_removed"]).hex() == float(want_res["time_removed"]).hex()
-        assert float(r["saved_pct"]).hex() == float(want_res["saved_pct"]).hex()
+        assert r["chunks"] == 8
+        _check_job(r, pooled, want_seg, want_res)
+
+    # ---- a batch of videos: BatchProcessor-shaped run (S streams x T workers, one job consumer)
+    cases = {path: (pooled, want_seg, want_res)}
+    paths = [path]
+    for k, (seed, nn, still) in enumerate([(21, 450, False), (22, 600, False), (23, 300, True), (24, 750, False)]):
+        sp, fr, tk, pth = _make_stream_file(tmp_path, f"b{k}.mtmv", seed, nn, still)
+        mpk = m.MergeParams(duration=nn / sp.fps, max_gap_sec=2.0, padding_sec=0.5, min_savings_pct=5.0)
+        pl, (ws, wr) = _reference_worker_loop(sp, fr, tk, nn / sp.fps, p, 4.0, 10.0, mpk)
+        cases[pth] = (pl, ws, wr)
+        paths.append(pth)
+    assert cases[paths[3]][2]["do_cut"] == -1                     # the still video: no motion, no job
+    for streams, threads in ((1, 2), (3, 2), (5, 1)):
+        out = subprocess.run([exe] + paths + ["--streams", str(streams), "--threads", str(threads),
+                                              "--outdir", str(tmp_path)], check=True, capture_output=True,
+                             text=True, env=env).stdout
+        jobs = [json.loads(ln) for ln in out.strip().splitlines()]
+        assert sorted(j["input"] for j in jobs) == sorted(pth for pth in paths if cases[pth][2]["do_cut"] >= 0)
+        for j in jobs:
+            _check_job(j, *cases[j["input"]])
