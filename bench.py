@@ -31,8 +31,8 @@ HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; ~6
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--frames", type=int, default=4096, help="frames per GPU per step")
     ap.add_argument("--streams", type=int, default=8, help="streams per GPU (frames split evenly)")
     ap.add_argument("--distinct", type=int, default=60, help="distinct generated frames per GPU (tiled)")

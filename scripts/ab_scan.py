@@ -66,7 +66,18 @@ def main():
             plan = s.plan
             scanners.append((name, s, plan, torch.empty(frames, dtype=torch.uint8, device=dev), []))
         ref = None
-        for r in range(rounds + 2):
+        if os.environ.get("AB_NOSYNC") == "1":
+            # back-to-back launches, no host sync in between (the bench.py regime)
+            for name, s, plan, fl, times in scanners:
+                evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(rounds + 2)]
+                for e0, e1 in evs:
+                    e0.record()
+                    s.check_frames_device(d_mv, d_off, None, fl)
+                    e1.record()
+                torch.cuda.synchronize()
+                times.extend(e0.elapsed_time(e1) for e0, e1 in evs[2:])
+                ref = fl.clone() if ref is None else ref
+        for r in range(0 if os.environ.get("AB_NOSYNC") == "1" else rounds + 2):
             for name, s, plan, fl, times in scanners:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()

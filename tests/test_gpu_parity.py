@@ -519,3 +519,33 @@ def test_cpp_host_pipeline_scan_file(tmp_path):
         assert sorted(j["input"] for j in jobs) == sorted(pth for pth in paths if cases[pth][2]["do_cut"] >= 0)
         for j in jobs:
             _check_job(j, *cases[j["input"]])
+
+
+def test_scan_device_unaligned_base_and_offset_clamp(gpu_scanner_factory):
+    """The record array may start at any 4-byte boundary (sub-views of a larger buffer), and
+    frame offsets beyond n_records are clamped instead of read (a bad offset must not fault)."""
+    import torch
+    rng = np.random.RandomState(4)
+    p = ob.params_from_config(1920, 1080, vectors_needed=1, clusters_needed=1)
+    s = gpu_scanner_factory(p)
+    mv, off, sd = synth.random_frames(rng, 40, 2500, 1920, 1080)
+    want = ob.scan_frames(p, mv, off, None)
+    raw = torch.from_numpy(mv.view(np.uint8).copy())
+    for shift in (4, 8, 12, 20):
+        buf = torch.zeros(raw.numel() + 64, dtype=torch.uint8, device="cuda")
+        view = buf[shift:shift + raw.numel()]
+        view.copy_(raw)
+        assert view.data_ptr() % 16 == shift % 16
+        got = s.check_frames_device(view, torch.from_numpy(off.astype(np.int64)).cuda())
+        assert np.array_equal(got.cpu().numpy(), want), shift
+    # clamp: pretend the array holds only the records of the first 25 frames
+    n_keep = int(off[25])
+    d_mv = raw[: n_keep * 40].cuda()
+    got = s.check_frames_device(d_mv, torch.from_numpy(off.astype(np.int64)).cuda()).cpu().numpy()
+    off_clamped = np.minimum(off, n_keep)
+    assert np.array_equal(got, ob.scan_frames(p, mv[:n_keep], off_clamped, None))
+    # an unaligned (odd) base is rejected, not dereferenced
+    bad = torch.zeros(raw.numel() + 8, dtype=torch.uint8, device="cuda")[1:1 + raw.numel()]
+    with pytest.raises(m.MtgpuError) as ei:
+        s.check_frames_device(bad, torch.from_numpy(off.astype(np.int64)).cuda())
+    assert ei.value.code == 1
