@@ -179,6 +179,28 @@ int mtgpu_pipe_collect(mtgpu_pipe *pipe, mtgpu_batch **out, const uint8_t **flag
                        const double **pts, const uint64_t **tags, uint32_t *n_frames);
 int mtgpu_pipe_release(mtgpu_pipe *pipe, mtgpu_batch *batch);
 
+/* ---------------------------------------------------------------------------
+ * Multi-GPU exchange for hosts that run one process per GPU without torch.distributed:
+ * thin wrappers over RCCL (loaded lazily; librccl.so.1 must be installed).  The path has
+ * exactly one exchange step — the per-GPU segment lists (or motion timestamps) after the
+ * scan — so one all-gather of fixed-size records is all that is exported.  The reference has
+ * no counterpart (single process, std::mutex pooling: src/task_queue.cpp:43-57).
+ *
+ *   rank 0: mtgpu_comm_unique_id(id)  -> ship the 128 bytes to the other ranks by any means
+ *   all   : mtgpu_comm_create(rank, n_ranks, id, device, &comm)
+ *   all   : mtgpu_gather_segments(comm, d_send, bytes, d_recv, stream)   [d_recv: n_ranks*bytes]
+ */
+#define MTGPU_UNIQUE_ID_BYTES 128
+typedef struct mtgpu_comm mtgpu_comm;
+int mtgpu_comm_unique_id(void *id_out /* MTGPU_UNIQUE_ID_BYTES */);
+int mtgpu_comm_create(int rank, int n_ranks, const void *id, int device, mtgpu_comm **out);
+void mtgpu_comm_destroy(mtgpu_comm *comm);
+/* All-gather `bytes_per_rank` bytes from every rank's d_send into d_recv (rank-major),
+ * asynchronous on `stream`.  Typically d_send is the packed {segments, mt_merge_result} block
+ * of this rank's streams. */
+int mtgpu_gather_segments(mtgpu_comm *comm, const void *d_send, uint64_t bytes_per_rank,
+                          void *d_recv, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -89,6 +89,10 @@ ABI = {
     "mtgpu_pipe_collect": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                      C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint32)]),
     "mtgpu_pipe_release": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mtgpu_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "mtgpu_comm_create": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "mtgpu_comm_destroy": (None, [C.c_void_p]),
+    "mtgpu_gather_segments": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
 }
 
 _lib = None

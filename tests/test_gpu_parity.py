@@ -549,3 +549,36 @@ def test_scan_device_unaligned_base_and_offset_clamp(gpu_scanner_factory):
     with pytest.raises(m.MtgpuError) as ei:
         s.check_frames_device(bad, torch.from_numpy(off.astype(np.int64)).cuda())
     assert ei.value.code == 1
+
+
+def test_c_abi_gather_single_rank(gpu_scanner_factory):
+    """mtgpu_comm_* / mtgpu_gather_segments (RCCL wrappers of the C ABI) with a 1-rank
+    communicator: the packed segment block comes back unchanged.  (N > 1 needs N GPUs; the
+    N-rank packing/assembly logic is covered by tests/test_dist_gloo.py.)"""
+    import ctypes as C
+    import torch
+    from mvtrim_amd import dist as mdist
+    lib = m.load_library()
+    uid = (C.c_char * 128)()
+    m._abi.check(lib.mtgpu_comm_unique_id(uid))
+    comm = C.c_void_p()
+    m._abi.check(lib.mtgpu_comm_create(0, 1, uid, 0, C.byref(comm)))
+    try:
+        s = gpu_scanner_factory(ob.params_from_config(1920, 1080))
+        flags = torch.from_numpy((np.arange(600) % 97 < 20).astype(np.uint8)).cuda()
+        pts = torch.from_numpy(np.arange(600) / 30.0).cuda()
+        soff = torch.tensor([0, 200, 600], dtype=torch.int64, device="cuda")
+        mp = np.concatenate([m.MergeParams(duration=200 / 30.0, max_gap_sec=1.0).to_record(),
+                             m.MergeParams(duration=400 / 30.0, max_gap_sec=1.0).to_record()])
+        seg, res = s.merge_streams_device(flags, pts, soff, torch.from_numpy(mp.view(np.uint8).copy()).cuda(),
+                                          True, 16)
+        packed = mdist.pack_segment_lists(seg, res)
+        recv = torch.zeros((1,) + tuple(packed.shape), dtype=torch.uint8, device="cuda")
+        st = torch.cuda.current_stream().cuda_stream
+        m._abi.check(lib.mtgpu_gather_segments(comm, packed.data_ptr(), packed.numel(), recv.data_ptr(), st))
+        torch.cuda.synchronize()
+        assert torch.equal(recv[0], packed)
+        lists = mdist.assemble_stream_lists(recv, 16, [2])
+        assert len(lists) == 2 and int(lists[0]["result"]["n_segments"]) >= 1
+    finally:
+        lib.mtgpu_comm_destroy(comm)
