@@ -196,8 +196,12 @@ def main():
             except Exception:
                 traffic = None
         cpu = None
+        # the batch is the generated tile repeated: so must be its flags (checks every frame of the
+        # 5 GB batch, not only the first tile, against the oracle-verified tile flags below)
+        tile_flags = flags_host[: a.distinct]
+        assert np.array_equal(flags_host, np.tile(tile_flags, reps)[: a.frames]), "flags are not tile-periodic"
         if world == 1 and a.cpu_seconds > 0:
-            cpu = cpu_baseline(params, mv, off, flags_host[: a.distinct], a.cpu_seconds, a.workload)
+            cpu = cpu_baseline(params, mv, off, tile_flags, a.cpu_seconds, a.workload)
         line = {
             "metric": "MV-scan frames/sec at 1080p grid" if a.workload.startswith("1080p") else "MV-scan frames/sec",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,

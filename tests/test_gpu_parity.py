@@ -257,7 +257,7 @@ def test_scan_batch_properties_full_size(gpu_scanner_factory):
     p = ob.params_from_config(1920, 1080)
     s = gpu_scanner_factory(p)
     want = ob.scan_frames(p, mv, off, None)
-    reps = 32                                   # 1024 frames, ~1.3 GB of records
+    reps = 128                                  # 4096 frames, 5.3 GB of records: offsets cross 2^32 bytes
     d_tile = torch.from_numpy(mv.view(np.uint8).copy()).cuda()
     d_mv = d_tile.repeat(reps)
     counts = np.diff(off.astype(np.int64))
