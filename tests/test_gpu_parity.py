@@ -582,3 +582,16 @@ def test_c_abi_gather_single_rank(gpu_scanner_factory):
         assert len(lists) == 2 and int(lists[0]["result"]["n_segments"]) >= 1
     finally:
         lib.mtgpu_comm_destroy(comm)
+
+
+def test_scan_host_window_of_larger_batch(gpu_scanner_factory):
+    """frame_off need not start at 0: scanning frames [a, b) of a larger packed array copies
+    only that window to the device (mtgpu_scan_frames rebases the record base)."""
+    rng = np.random.RandomState(12)
+    p = ob.params_from_config(1920, 1080, vectors_needed=1, clusters_needed=1)
+    s = gpu_scanner_factory(p)
+    mv, off, sd = synth.random_frames(rng, 60, 2000, 1920, 1080)
+    want = ob.scan_frames(p, mv, off, sd)
+    for a, b in [(0, 60), (10, 35), (59, 60), (17, 17)]:
+        got = s.check_frames(m.FrameBatch(mv, off[a:b + 1], None, sd[a:b]))
+        assert np.array_equal(got, want[a:b]), (a, b)
