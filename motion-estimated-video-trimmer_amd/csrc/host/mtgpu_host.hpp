@@ -235,7 +235,7 @@ class GpuMotionScanner {   // public shape of MotionScanner (motion_scanner.hpp:
   mtgpu_ctx *context() { return ctx_; }
 
   // cfg/grid derivation of MotionScanner::initialize (motion_scanner.cpp:184-199) + device setup
-  bool initialize(uint64_t batch_records = 1u << 20, uint32_t batch_frames = 256, int n_buffers = 3) {
+  bool initialize(uint64_t batch_records = 1u << 18, uint32_t batch_frames = 256, int n_buffers = 3) {
     mt_scan_params p;
     if (!ok(mtgpu_params_from_config(&p, src_.width(), src_.height(), Config::mv_threshold_sq(),
                                      Config::block_size(), Config::block_shift(), Config::vectors_needed(),
@@ -293,7 +293,8 @@ struct PipelineResult {
   mt_merge_result merge{};
   size_t motion_frames = 0;           // pooled timestamps before sort/unique (pipeline.cpp:294-295)
   int chunks = 0, threads = 0;
-  long seek_us = 0, decode_us = 0, analyze_us = 0;
+  long seek_us = 0, decode_us = 0, analyze_us = 0;   // summed over workers, as pipeline.cpp:229-233
+  long init_us = 0, scan_wall_us = 0;                // worker init (summed) / wall time of the scan phase
   std::string error;
 };
 
@@ -315,7 +316,8 @@ int run_scan_pipeline(MakeSource make_source, int num_threads, PipelineResult &o
   int chunk_id = 0;
   for (double t = 0; t < duration; t += chunk)                           // :163-167
     tasks.push({t, std::min(t + chunk, duration), chunk_id++});
-  std::atomic<long> seek_us{0}, decode_us{0}, analyze_us{0};
+  std::atomic<long> seek_us{0}, decode_us{0}, analyze_us{0}, init_us{0};
+  const auto wall0 = std::chrono::high_resolution_clock::now();
   std::mutex err_mu;
   std::vector<std::thread> workers;
   mtgpu_ctx *merge_ctx = nullptr;
@@ -324,6 +326,7 @@ int run_scan_pipeline(MakeSource make_source, int num_threads, PipelineResult &o
   std::vector<std::unique_ptr<FrameSource>> sources(num_threads);
   for (int i = 0; i < num_threads; ++i) {
     workers.emplace_back([&, i] {                                        // :186-235
+      const auto i0 = std::chrono::high_resolution_clock::now();
       sources[i] = make_source();
       scanners[i] = std::make_unique<GpuMotionScanner>(*sources[i], (device_base + i) % n_dev);
       if (!scanners[i]->initialize()) {                                  // :198-199 (here: reported)
@@ -331,6 +334,8 @@ int run_scan_pipeline(MakeSource make_source, int num_threads, PipelineResult &o
         out.error = scanners[i]->error();
         return;
       }
+      init_us += (long)std::chrono::duration_cast<std::chrono::microseconds>(
+                     std::chrono::high_resolution_clock::now() - i0).count();   // :195-206
       long s = 0, d = 0, a = 0;
       ScanTask task;
       while (tasks.pop(task)) {                                          // :216-223
@@ -344,7 +349,9 @@ int run_scan_pipeline(MakeSource make_source, int num_threads, PipelineResult &o
   for (auto &w : workers) w.join();
   out.chunks = chunk_id;
   out.threads = num_threads;
-  out.seek_us = seek_us; out.decode_us = decode_us; out.analyze_us = analyze_us;
+  out.seek_us = seek_us; out.decode_us = decode_us; out.analyze_us = analyze_us; out.init_us = init_us;
+  out.scan_wall_us = (long)std::chrono::duration_cast<std::chrono::microseconds>(
+                         std::chrono::high_resolution_clock::now() - wall0).count();
   if (!out.error.empty()) return 1;
   std::vector<double> timestamps = results.extract();
   out.motion_frames = timestamps.size();

@@ -595,3 +595,37 @@ def test_scan_host_window_of_larger_batch(gpu_scanner_factory):
     for a, b in [(0, 60), (10, 35), (59, 60), (17, 17)]:
         got = s.check_frames(m.FrameBatch(mv, off[a:b + 1], None, sd[a:b]))
         assert np.array_equal(got, want[a:b]), (a, b)
+
+
+def test_scan_fuzz_random_configs(gpu_scanner_factory):
+    """Randomised sweep: grid sizes, block settings, thresholds, vote / cluster needs, masks and
+    every counter form, each on ragged adversarial frames.  Bit-exact flags vs the oracle."""
+    rng = np.random.RandomState(20260104)
+    forms = [None, 1, 2, 4, 8, 108, 32]
+    n_cfg = 120
+    for it in range(n_cfg):
+        sh = int(rng.randint(0, 7))
+        bs = int(rng.choice([1 << sh, 16, 8]))
+        w, h = int(rng.randint(8, 4300)), int(rng.randint(8, 2400))
+        kw = dict(mv_threshold_sq=float(rng.choice([16.0, 4.0, 0.0, 1.0, 30.25, 1e4, float("nan")])),
+                  block_size=bs, block_shift=sh,
+                  vectors_needed=int(rng.choice([0, 1, 2, 3, 4, 5, 8, 9, 17, 255, 256 + 2])),
+                  clusters_needed=int(rng.choice([-1, 0, 1, 2, 3, 7, 50])),
+                  vertical_mask=float(rng.choice([0.0, 0.05, 0.1, 0.3, 0.49, 0.5])))
+        try:
+            p = ob.params_from_config(w, h, **kw)
+        except ValueError:
+            continue
+        if p.grid_w * p.grid_h > 1_500_000:         # keep the oracle fast
+            continue
+        try:
+            s = gpu_scanner_factory(p, force_fb=forms[it % len(forms)])
+        except m.MtgpuError as e:
+            assert e.code == 2, e                    # only MT_ERR_CAPACITY (grid row wider than LDS) is acceptable
+            continue
+        mv, off, sd = synth.random_frames(rng, 10, 2500, w, h, hot=float(rng.choice([0.1, 0.5, 0.9])))
+        junk_padding(mv, rng)
+        want = ob.scan_frames(p, mv, off, sd)
+        got = s.check_frames(m.FrameBatch(mv, off, None, sd))
+        assert np.array_equal(got, want), (it, w, h, kw, s.plan)
+        s.close()
