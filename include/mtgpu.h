@@ -83,6 +83,11 @@ typedef struct mtgpu_plan {
 } mtgpu_plan;
 int mtgpu_get_plan(const mtgpu_ctx *ctx, mtgpu_plan *out);
 
+/* Workgroups per frame along the record array: 0 = automatic (the default: split frames only
+ * when a batch has too few frames to fill the chip and the frames are large), or 1, 2, 4, 8.
+ * Results never depend on it. */
+int mtgpu_set_slices(mtgpu_ctx *ctx, int slices);
+
 /*
  * check_frame() over a device-resident batch — replaces the per-frame call at
  * src/motion_scanner.cpp:376 (body :217-295).

@@ -13,9 +13,8 @@ int hip_fail(hipError_t e, const char *what);
 
 int ctx_device(const mtgpu_ctx *c);
 int ctx_bands(const mtgpu_ctx *c);
-// Launch the scan for a device-resident batch on `st` (d_centres: n_frames words when bands > 1).
+// Launch the scan for a device-resident batch on `st`.
 int ctx_launch_scan(mtgpu_ctx *c, const void *d_mv, uint64_t n_records, const uint64_t *d_off,
-                    const uint8_t *d_sd, uint32_t n_frames, uint8_t *d_flags, unsigned int *d_centres,
-                    hipStream_t st);
+                    const uint8_t *d_sd, uint32_t n_frames, uint8_t *d_flags, hipStream_t st);
 
 }  // namespace mtgpu

@@ -74,6 +74,8 @@ struct mtgpu_ctx {
   int device;
   hipStream_t stream;    // private stream of the host-pointer entry points
   int variant = 0;       // MTGPU_VARIANT experiment knob
+  int slices_request = 0;  // 0 = auto, else 1/2/4/8 (mtgpu_set_slices, MTGPU_FORCE_SLICES)
+  int wide_chunk_rows = 0, wide_lds_bytes = 0;   // single-workgroup-per-CU layout (see make_plan)
   std::mutex mu;         // guards the staging buffers below
   DevBuf d_mv, d_off, d_sd, d_flags, d_misc;
 };
@@ -169,6 +171,11 @@ int make_plan(mtgpu_ctx *c, int lds_max, int cu_count) {
   // Two workgroups per CU hide each other's zero / cluster-test phases (measured +4 % on the
   // 960x540 grid): when only the mask buffer pushes a tile over half of LDS, chunk the cluster
   // test so that the tile fits 80 KB.
+  // That only helps when a launch has more work items than CUs; with fewer, one workgroup per
+  // CU runs anyway and the single-chunk layout is faster (5.87 vs 5.50 TB/s at 256 frames), so
+  // both layouts are kept and launch_scan_on picks per launch.
+  c->wide_chunk_rows = chunk_rows;
+  c->wide_lds_bytes = (int)lds_need(band_rows, chunk_rows, k.gw, k.W, fb, nullptr);
   {
     const size_t half = 80u * 1024u;
     const size_t cnt_only = lds_need(band_rows, -2, k.gw, k.W, fb, nullptr);
@@ -178,7 +185,7 @@ int make_plan(mtgpu_ctx *c, int lds_max, int cu_count) {
     }
   }
   const int fchunk = env_int("MTGPU_FORCE_CHUNK", 0);         // experiments: smaller mask buffer
-  if (fchunk >= 1 && fchunk < chunk_rows) chunk_rows = fchunk;
+  if (fchunk >= 1 && fchunk < chunk_rows) { chunk_rows = fchunk; c->wide_chunk_rows = fchunk; c->wide_lds_bytes = (int)lds_need(band_rows, fchunk, k.gw, k.W, fb, nullptr); }
   k.fb = fb;
   k.band_rows = band_rows;
   k.chunk_rows = chunk_rows;
@@ -200,14 +207,38 @@ int make_plan(mtgpu_ctx *c, int lds_max, int cu_count) {
   c->plan.cu_count = cu_count;
   c->plan.chunk_rows = chunk_rows;
   c->variant = env_int("MTGPU_VARIANT", 0);
+  {
+    const int fs = env_int("MTGPU_FORCE_SLICES", 0);
+    c->slices_request = (fs == 1 || fs == 2 || fs == 4 || fs == 8) ? fs : 0;
+  }
+  k.slices = 1;
   c->plan.counter_mode = mode;
   c->plan._pad = 0;
   return MT_OK;
 }
 
+// Slices per frame for this launch.  Measured (scripts/ab_scan.py, AB_SET=slices): the hand-off
+// (tile write + agent-scope release/acquire + tile reads) costs several microseconds per
+// workgroup, so splitting pays only for batches that leave most CUs idle AND whose frames are
+// large: 64 frames of the 960x540 grid +47 % with 4 slices, 64 4K frames +8 % with 2; every
+// other shape loses (256 1080p frames: -40 % with 2).  Auto therefore never exceeds one
+// workgroup per CU and keeps >= 32768 records (1.3 MB) per slice.
+int choose_slices(const mtgpu_ctx *c, uint64_t n_records, uint32_t n_frames) {
+  if (c->k.bands != 1) return 1;
+  int s = c->slices_request;
+  if (s == 0) {                                               // auto
+    const uint64_t cus = (uint64_t)(c->plan.cu_count > 0 ? c->plan.cu_count : 256);
+    const uint64_t avg = n_records / (n_frames ? n_frames : 1);
+    s = 1;
+    while (s < 8 && (uint64_t)n_frames * (uint64_t)(2 * s) <= cus && avg / (uint64_t)(2 * s) >= 32768ull) s *= 2;
+  }
+  return (s == 2 || s == 4 || s == 8) ? s : 1;
+}
+
+// Launches the scan on `st`; scratch (band centre counts, slice tiles + tickets) is allocated
+// and freed stream-ordered, so concurrent callers share nothing.
 int launch_scan_on(mtgpu_ctx *c, const void *d_mv, uint64_t n_records, const uint64_t *d_off,
-                   const uint8_t *d_sd, uint32_t n_frames, uint8_t *d_flags, unsigned int *d_centres,
-                   hipStream_t st) {
+                   const uint8_t *d_sd, uint32_t n_frames, uint8_t *d_flags, hipStream_t st) {
   mtgpu::ScanLaunch L;
   L.mv = static_cast<const unsigned char *>(d_mv);
   L.n_records = n_records;
@@ -215,15 +246,43 @@ int launch_scan_on(mtgpu_ctx *c, const void *d_mv, uint64_t n_records, const uin
   L.has_sd = d_sd;
   L.n_frames = n_frames;
   L.flags = d_flags;
-  L.frame_centres = d_centres;
+  L.frame_centres = nullptr;
+  L.slice_ws = nullptr;
+  L.tickets = nullptr;
   L.k = c->k;
+  L.k.slices = choose_slices(c, n_records, n_frames);
   L.block = c->plan.block_threads;
   L.variant = c->variant;
   L.lds_bytes = c->plan.lds_bytes;
+  if (c->wide_lds_bytes > c->plan.lds_bytes &&
+      (uint64_t)n_frames * (uint64_t)L.k.bands * (uint64_t)L.k.slices <= (uint64_t)c->plan.cu_count) {
+    L.k.chunk_rows = c->wide_chunk_rows;        // at most one workgroup per CU: bigger mask buffer, fewer chunks
+    L.k.mask_rows = c->wide_chunk_rows + 2;
+    L.lds_bytes = c->wide_lds_bytes;
+  }
   L.stream = st;
+  void *scratch = nullptr;
+  size_t bytes = 0;
+  if (L.k.bands > 1) bytes = sizeof(unsigned int) * (size_t)n_frames;
+  if (L.k.slices > 1)
+    bytes = sizeof(unsigned int) * ((size_t)n_frames * (size_t)L.k.slices * (size_t)L.k.cnt_words + (size_t)n_frames + 4);
+  if (bytes) {
+    hipError_t e = hipMallocAsync(&scratch, bytes, st);
+    if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(scan scratch)");
+    if (L.k.bands > 1) L.frame_centres = static_cast<unsigned int *>(scratch);
+    if (L.k.slices > 1) {
+      L.slice_ws = static_cast<unsigned int *>(scratch);
+      L.tickets = L.slice_ws + (((size_t)n_frames * (size_t)L.k.slices * (size_t)L.k.cnt_words + 3) & ~(size_t)3);
+    }
+  }
   hipError_t e = mtgpu::launch_scan(L);
-  if (e != hipSuccess) return hip_fail(e, "scan launch");
-  return MT_OK;
+  int rc = MT_OK;
+  if (e != hipSuccess) rc = hip_fail(e, "scan launch");
+  if (scratch) {
+    hipError_t e2 = hipFreeAsync(scratch, st);
+    if (rc == MT_OK && e2 != hipSuccess) rc = hip_fail(e2, "hipFreeAsync");
+  }
+  return rc;
 }
 
 }  // namespace
@@ -232,9 +291,8 @@ namespace mtgpu {
 int ctx_device(const mtgpu_ctx *c) { return c->device; }
 int ctx_bands(const mtgpu_ctx *c) { return c->k.bands; }
 int ctx_launch_scan(mtgpu_ctx *c, const void *d_mv, uint64_t n_records, const uint64_t *d_off,
-                    const uint8_t *d_sd, uint32_t n_frames, uint8_t *d_flags, unsigned int *d_centres,
-                    hipStream_t st) {
-  return launch_scan_on(c, d_mv, n_records, d_off, d_sd, n_frames, d_flags, d_centres, st);
+                    const uint8_t *d_sd, uint32_t n_frames, uint8_t *d_flags, hipStream_t st) {
+  return launch_scan_on(c, d_mv, n_records, d_off, d_sd, n_frames, d_flags, st);
 }
 }  // namespace mtgpu
 
@@ -329,16 +387,16 @@ int mtgpu_scan_frames_device(mtgpu_ctx *c, const void *d_mv, uint64_t n_records,
   if (n_records > 0 && !d_mv) return fail(MT_ERR_INVALID, "mv is NULL with n_records > 0");
   if (((uintptr_t)d_mv & 3u) != 0) return fail(MT_ERR_INVALID, "mv must be 4-byte aligned");
   HIP_TRY(hipSetDevice(c->device));
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  unsigned int *centres = nullptr;
-  if (c->k.bands > 1)
-    HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&centres), sizeof(unsigned int) * (size_t)n_frames, st));
-  int rc = launch_scan_on(c, d_mv, n_records, d_frame_off, d_has_sd, n_frames, d_flags, centres, st);
-  if (centres) {
-    hipError_t e = hipFreeAsync(centres, st);
-    if (rc == MT_OK && e != hipSuccess) rc = hip_fail(e, "hipFreeAsync");
-  }
-  return rc;
+  return launch_scan_on(c, d_mv, n_records, d_frame_off, d_has_sd, n_frames, d_flags,
+                        static_cast<hipStream_t>(stream));
+}
+
+int mtgpu_set_slices(mtgpu_ctx *c, int slices) {
+  if (!c) return fail(MT_ERR_INVALID, "ctx is NULL");
+  if (slices != 0 && slices != 1 && slices != 2 && slices != 4 && slices != 8)
+    return fail(MT_ERR_INVALID, "slices must be 0 (auto), 1, 2, 4 or 8");
+  c->slices_request = slices;
+  return MT_OK;
 }
 
 int mtgpu_scan_frames(mtgpu_ctx *c, const mt_mv *mv, const uint64_t *frame_off,
@@ -360,7 +418,6 @@ int mtgpu_scan_frames(mtgpu_ctx *c, const mt_mv *mv, const uint64_t *frame_off,
   if ((rc = c->d_off.reserve(sizeof(uint64_t) * ((size_t)n_frames + 1))) != MT_OK) return rc;
   if ((rc = c->d_flags.reserve(n_frames)) != MT_OK) return rc;
   if (has_sd && (rc = c->d_sd.reserve(n_frames)) != MT_OK) return rc;
-  if (c->k.bands > 1 && (rc = c->d_misc.reserve(sizeof(unsigned int) * (size_t)n_frames)) != MT_OK) return rc;
 
   hipStream_t st = c->stream;
   if (n_records)
@@ -372,7 +429,7 @@ int mtgpu_scan_frames(mtgpu_ctx *c, const mt_mv *mv, const uint64_t *frame_off,
   const unsigned char *base = static_cast<const unsigned char *>(c->d_mv.p) - (size_t)r_begin * MT_MV_BYTES;
   rc = launch_scan_on(c, base, r_end, static_cast<const uint64_t *>(c->d_off.p),
                       has_sd ? static_cast<const uint8_t *>(c->d_sd.p) : nullptr, n_frames,
-                      static_cast<uint8_t *>(c->d_flags.p), static_cast<unsigned int *>(c->d_misc.p), st);
+                      static_cast<uint8_t *>(c->d_flags.p), st);
   if (rc != MT_OK) return rc;
   HIP_TRY(hipMemcpyAsync(flags, c->d_flags.p, n_frames, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));

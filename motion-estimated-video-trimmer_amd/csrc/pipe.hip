@@ -26,7 +26,6 @@ struct mtgpu_batch {
   uint64_t *d_off = nullptr;
   uint8_t *d_sd = nullptr;
   uint8_t *d_flags = nullptr;
-  unsigned int *d_centres = nullptr;
   uint64_t cap_records = 0, n_records = 0;
   uint32_t cap_frames = 0, n_frames = 0;
   hipStream_t stream = nullptr;
@@ -60,7 +59,6 @@ void free_batch(mtgpu_batch *b) {
   if (b->d_off) (void)hipFree(b->d_off);
   if (b->d_sd) (void)hipFree(b->d_sd);
   if (b->d_flags) (void)hipFree(b->d_flags);
-  if (b->d_centres) (void)hipFree(b->d_centres);
   if (b->done) (void)hipEventDestroy(b->done);
   if (b->stream) (void)hipStreamDestroy(b->stream);
   delete b;
@@ -72,7 +70,7 @@ void free_batch(mtgpu_batch *b) {
     if (_e != hipSuccess) { rc = hip_fail(_e, #expr); goto bad; }    \
   } while (0)
 
-int alloc_batch(mtgpu_batch **out, uint64_t max_records, uint32_t max_frames, int bands) {
+int alloc_batch(mtgpu_batch **out, uint64_t max_records, uint32_t max_frames) {
   int rc = MT_OK;
   mtgpu_batch *b = new (std::nothrow) mtgpu_batch();
   if (!b) return fail(MT_ERR_NOMEM, "out of host memory");
@@ -91,7 +89,6 @@ int alloc_batch(mtgpu_batch **out, uint64_t max_records, uint32_t max_frames, in
     PIPE_TRY(hipMalloc(reinterpret_cast<void **>(&b->d_off), sizeof(uint64_t) * (nf + 1)));
     PIPE_TRY(hipMalloc(reinterpret_cast<void **>(&b->d_sd), nf + 1));
     PIPE_TRY(hipMalloc(reinterpret_cast<void **>(&b->d_flags), nf + 1));
-    if (bands > 1) PIPE_TRY(hipMalloc(reinterpret_cast<void **>(&b->d_centres), sizeof(unsigned int) * (nf + 1)));
     PIPE_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
     PIPE_TRY(hipEventCreateWithFlags(&b->done, hipEventDisableTiming));
   }
@@ -120,7 +117,7 @@ int mtgpu_pipe_create(mtgpu_ctx *ctx, uint64_t max_records_per_batch, uint32_t m
   p->ctx = ctx;
   for (int i = 0; i < n_buffers; ++i) {
     mtgpu_batch *b = nullptr;
-    int rc = alloc_batch(&b, max_records_per_batch, max_frames_per_batch, mtgpu::ctx_bands(ctx));
+    int rc = alloc_batch(&b, max_records_per_batch, max_frames_per_batch);
     if (rc != MT_OK) { mtgpu_pipe_destroy(p); return rc; }
     b->owner = p;
     p->bufs.push_back(b);
@@ -191,8 +188,7 @@ int mtgpu_pipe_submit(mtgpu_pipe *p, mtgpu_batch *b) {
     if (e != hipSuccess) return hip_fail(e, "H2D offsets");
     e = hipMemcpyAsync(b->d_sd, b->h_sd, b->n_frames, hipMemcpyHostToDevice, st);
     if (e != hipSuccess) return hip_fail(e, "H2D has_sd");
-    int rc = mtgpu::ctx_launch_scan(p->ctx, b->d_mv, b->n_records, b->d_off, b->d_sd, b->n_frames, b->d_flags,
-                                    b->d_centres, st);
+    int rc = mtgpu::ctx_launch_scan(p->ctx, b->d_mv, b->n_records, b->d_off, b->d_sd, b->n_frames, b->d_flags, st);
     if (rc != MT_OK) return rc;
     e = hipMemcpyAsync(b->h_flags, b->d_flags, b->n_frames, hipMemcpyDeviceToHost, st);
     if (e != hipSuccess) return hip_fail(e, "D2H flags");

@@ -22,6 +22,7 @@ struct ScanK {
   int mode;                // 0 ADD32 (fb 32), 1 UNARY thermometer (vec_need <= fb), 2 CAS (fb 8)
   unsigned int active_min; // cell active <=> field value >= active_min
   int chunk_rows;          // centre rows per phase-2 chunk (mask buffer holds chunk_rows + 2 rows)
+  int slices;              // workgroups per frame along the record array (1 = none; needs bands == 1)
   int cnt_words;           // LDS counter words per workgroup ((band_rows + 2) * gw fields, padded to 4)
   int mask_rows;           // chunk_rows + 2
 };
@@ -34,6 +35,8 @@ struct ScanLaunch {
   unsigned int n_frames;
   unsigned char *flags;
   unsigned int *frame_centres;  // n_frames words, only when k.bands > 1
+  unsigned int *slice_ws;       // n_frames * slices * cnt_words words, only when k.slices > 1
+  unsigned int *tickets;        // n_frames words (zeroed by launch_scan), only when k.slices > 1
   ScanK k;
   int block;
   int variant;             // experiment knob (MTGPU_VARIANT), 0 = shipped kernel

@@ -101,6 +101,30 @@ __device__ __forceinline__ unsigned int count_of(const unsigned int *cnt, unsign
   }
 }
 
+// Field-wise saturating sum of two packed counter words (slice combine).
+template <int FB, int MODE>
+__device__ __forceinline__ unsigned int combine_words(unsigned int a, unsigned int b, unsigned int cap) {
+  if constexpr (MODE == MODE_ADD32) {
+    return a + b;
+  } else {
+    if (b == 0u) return a;
+    if (a == 0u) return b;
+    constexpr unsigned int FM = (1u << FB) - 1u;
+    unsigned int r = 0u;
+#pragma unroll
+    for (int sh = 0; sh < 32; sh += FB) {
+      const unsigned int fa = (a >> sh) & FM, fb = (b >> sh) & FM;
+      if constexpr (MODE == MODE_UNARY) {
+        const unsigned int c = min(cap, (unsigned int)__popc(fa) + (unsigned int)__popc(fb));
+        r |= ((1u << c) - 1u) << sh;
+      } else {
+        r |= min(cap, fa + fb) << sh;
+      }
+    }
+    return r;
+  }
+}
+
 // Threshold + cell mapping + vote for one record (src/motion_scanner.cpp:246-267).
 template <int FB, int MODE>
 __device__ __forceinline__ void vote(const u32x3 d, const ScanK &k, int t0, int t1,
@@ -126,20 +150,31 @@ __global__ __launch_bounds__(BLOCK) void scan_frames_kernel(
     const unsigned char *__restrict__ mv, unsigned long long n_records,
     const unsigned long long *__restrict__ frame_off, const unsigned char *__restrict__ has_sd,
     unsigned int item0, ScanK k, unsigned char *__restrict__ flags,
-    unsigned int *__restrict__ frame_centres) {
+    unsigned int *__restrict__ frame_centres, unsigned int *slice_ws, unsigned int *tickets) {
   extern __shared__ __attribute__((aligned(16))) unsigned int lds[];
   const int tid = threadIdx.x;
   const unsigned int item = item0 + blockIdx.x;
-  const unsigned int f = item / (unsigned int)k.bands;
-  const int band = (int)(item - f * (unsigned int)k.bands);
+  // item -> (frame, band) or (frame, slice): bands and slices are never both > 1
+  const unsigned int per_frame = (unsigned int)(k.bands * k.slices);
+  const unsigned int f = item / per_frame;
+  const int sub = (int)(item - f * per_frame);
+  const int band = k.slices > 1 ? 0 : sub;
+  const int slice = k.slices > 1 ? sub : 0;
 
   unsigned long long r0 = frame_off[f], r1 = frame_off[f + 1];
   r1 = r1 < n_records ? r1 : n_records;
   r0 = r0 < r1 ? r0 : r1;
   const bool sd = has_sd ? (has_sd[f] != 0) : (r1 > r0);
   if (!sd) {                                   // :219-221 — no side data: false
-    if (k.bands == 1 && tid == 0) flags[f] = 0;
+    if (k.bands == 1 && slice == 0 && tid == 0) flags[f] = 0;
     return;                                    // (bands > 1: finalize kernel writes 0)
+  }
+  if (k.slices > 1) {                          // this workgroup's share of the frame's records
+    const unsigned long long n = r1 - r0, per = (n + (unsigned long long)k.slices - 1ull) / (unsigned long long)k.slices;
+    const unsigned long long a = r0 + min(n, per * (unsigned long long)slice);
+    const unsigned long long b = r0 + min(n, per * (unsigned long long)(slice + 1));
+    r0 = a;
+    r1 = b;
   }
 
   // Band geometry: centres [c0,c1), tracked counter rows [t0,t1).
@@ -154,6 +189,7 @@ __global__ __launch_bounds__(BLOCK) void scan_frames_kernel(
   unsigned long long *mask =
       reinterpret_cast<unsigned long long *>(lds + k.cnt_words);   // [chunk_rows+2][W]
   unsigned int *total = reinterpret_cast<unsigned int *>(mask + (size_t)k.mask_rows * W);
+  unsigned int *ticket = total + 1;
 
   // ---- phase 0: zero counters and the centre total
   {
@@ -208,6 +244,49 @@ __global__ __launch_bounds__(BLOCK) void scan_frames_kernel(
     for (; i < n; i += BLOCK) vote<FB, MODE>(load_fields<VAR>(base + i * 40ull), k, t0, t1, cnt);
   }
   __syncthreads();
+
+  // ---- slices: publish this partial grid; the LAST workgroup of the frame to arrive sums them
+  // (no workgroup ever waits for another: nothing to deadlock on).  Hand-off = plain stores ->
+  // every wave drains -> barrier -> agent-scope release -> ticket; the last arriver does one
+  // agent-scope acquire before plain loads (cdna_hip_programming.md, Guideline 16).
+  if (k.slices > 1) {
+    const size_t words = (size_t)k.cnt_words;
+    unsigned int *mine = slice_ws + ((size_t)f * (size_t)k.slices + (size_t)slice) * words;
+    {
+      const u32x4 *c4 = reinterpret_cast<const u32x4 *>(cnt);
+      u32x4 *g4 = reinterpret_cast<u32x4 *>(mine);
+      for (int i = tid; i < (k.cnt_words >> 2); i += BLOCK) g4[i] = c4[i];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      *ticket = __hip_atomic_fetch_add(&tickets[f], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (*ticket != (unsigned int)(k.slices - 1)) return;       // not the last: done
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    for (int s2 = 0; s2 < k.slices; ++s2) {
+      if (s2 == slice) continue;
+      const u32x4 *g4 = reinterpret_cast<const u32x4 *>(slice_ws + ((size_t)f * (size_t)k.slices + (size_t)s2) * words);
+      u32x4 *c4 = reinterpret_cast<u32x4 *>(cnt);
+      for (int i = tid; i < (k.cnt_words >> 2); i += BLOCK) {
+        const u32x4 o = g4[i];
+        u32x4 m = c4[i];
+        m.x = combine_words<FB, MODE>(m.x, o.x, k.vec_need);
+        m.y = combine_words<FB, MODE>(m.y, o.y, k.vec_need);
+        m.z = combine_words<FB, MODE>(m.z, o.z, k.vec_need);
+        m.w = combine_words<FB, MODE>(m.w, o.w, k.vec_need);
+        c4[i] = m;
+      }
+    }
+    __syncthreads();
+  }
 
   // ---- phase 2: chunks of centre rows [c0+q0, c0+q0+qn); mask row j <-> grid row c0+q0-1+j
   const int crows = c1 - c0;
@@ -286,12 +365,14 @@ static hipError_t launch_one(const ScanLaunch &L) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, L.lds_bytes);
   if (e != hipSuccess) return e;
-  const unsigned long long items = (unsigned long long)L.n_frames * (unsigned long long)L.k.bands;
+  const unsigned long long items =
+      (unsigned long long)L.n_frames * (unsigned long long)L.k.bands * (unsigned long long)L.k.slices;
   const unsigned long long chunk = 1ull << 30;
   for (unsigned long long i0 = 0; i0 < items; i0 += chunk) {
     const unsigned int n = (unsigned int)((items - i0 < chunk) ? (items - i0) : chunk);
     hipLaunchKernelGGL(kern, dim3(n), dim3(BLOCK), L.lds_bytes, L.stream, L.mv, L.n_records,
-                       L.frame_off, L.has_sd, (unsigned int)i0, L.k, L.flags, L.frame_centres);
+                       L.frame_off, L.has_sd, (unsigned int)i0, L.k, L.flags, L.frame_centres, L.slice_ws,
+                       L.tickets);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
@@ -332,6 +413,11 @@ hipError_t launch_scan(const ScanLaunch &L) {
   hipError_t e;
   if (L.k.bands > 1) {
     e = hipMemsetAsync(L.frame_centres, 0, sizeof(unsigned int) * (size_t)L.n_frames, L.stream);
+    if (e != hipSuccess) return e;
+  }
+  if (L.k.slices > 1) {
+    if (L.k.bands != 1 || !L.slice_ws || !L.tickets) return hipErrorInvalidValue;
+    e = hipMemsetAsync(L.tickets, 0, sizeof(unsigned int) * (size_t)L.n_frames, L.stream);
     if (e != hipSuccess) return e;
   }
   switch (L.block) {

@@ -197,6 +197,10 @@ class MotionScanner:
         check(self._lib.mtgpu_get_plan(self._ctx, C.byref(p)))
         return {n: getattr(p, n) for n, _ in PlanC._fields_ if not n.startswith("_")}
 
+    def set_slices(self, slices: int):
+        """Workgroups per frame: 0 = automatic (default), or 1 / 2 / 4 / 8.  Never changes results."""
+        check(self._lib.mtgpu_set_slices(self._ctx, int(slices)))
+
     # ---------------------------------------------------------------- scan
     def check_frames(self, batch: FrameBatch) -> np.ndarray:
         """check_frame() for every frame of a host batch -> uint8 flags [F]."""

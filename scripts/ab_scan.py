@@ -21,6 +21,8 @@ VARIANTS_FINE = [("default", dict()), ("chunk64", dict(MTGPU_FORCE_CHUNK="64")),
                  ("chunk160/b512", dict(MTGPU_FORCE_CHUNK="160", MTGPU_FORCE_BLOCK="512")),
                  ("fb2", dict(MTGPU_FORCE_FB="2"))]
 VARIANTS_KERNEL = [("v%d" % v, dict(MTGPU_VARIANT=str(v))) for v in (0, 1, 2, 4, 8, 9, 10, 12, 3, 11, 6, 14)]
+VARIANTS_SLICES = [("auto", dict()), ("s1", dict(MTGPU_FORCE_SLICES="1")), ("s2", dict(MTGPU_FORCE_SLICES="2")),
+                   ("s4", dict(MTGPU_FORCE_SLICES="4")), ("s8", dict(MTGPU_FORCE_SLICES="8"))]
 VARIANTS = [("fb32", dict(MTGPU_FORCE_FB="32")), ("fb2", dict(MTGPU_FORCE_FB="2")),
             ("fb32/b512", dict(MTGPU_FORCE_FB="32", MTGPU_FORCE_BLOCK="512")),
             ("fb2/b512", dict(MTGPU_FORCE_FB="2", MTGPU_FORCE_BLOCK="512")),
@@ -53,9 +55,9 @@ def main():
         d_off = torch.from_numpy(off_big).to(dev)
         alg = 40 * int(off_big[-1]) + 9 * frames
         scanners = []
-        vset = {"fine": VARIANTS_FINE, "kernel": VARIANTS_KERNEL}.get(os.environ.get("AB_SET"), VARIANTS)
+        vset = {"fine": VARIANTS_FINE, "kernel": VARIANTS_KERNEL, "slices": VARIANTS_SLICES}.get(os.environ.get("AB_SET"), VARIANTS)
         for name, env in vset:
-            for k in ("MTGPU_FORCE_FB", "MTGPU_FORCE_BLOCK", "MTGPU_FORCE_CHUNK", "MTGPU_VARIANT"):
+            for k in ("MTGPU_FORCE_FB", "MTGPU_FORCE_BLOCK", "MTGPU_FORCE_CHUNK", "MTGPU_VARIANT", "MTGPU_FORCE_SLICES"):
                 os.environ.pop(k, None)
             os.environ.update(env)
             try:

@@ -629,3 +629,69 @@ def test_scan_fuzz_random_configs(gpu_scanner_factory):
         got = s.check_frames(m.FrameBatch(mv, off, None, sd))
         assert np.array_equal(got, want), (it, w, h, kw, s.plan)
         s.close()
+
+
+@pytest.mark.parametrize("slices", [2, 4, 8])
+@pytest.mark.parametrize("force_fb", [None, 1, 2, 4, 8, 108])
+def test_scan_frame_slices(gpu_scanner_factory, slices, force_fb):
+    """Several workgroups per frame (record-array slices, last arriver sums the partial LDS tiles):
+    results must not depend on the slice count, for every counter form."""
+    rng = np.random.RandomState(slices * 100 + (force_fb or 0))
+    for vec, clus in ((1, 1), (2, 2), (4, 3), (8, 2), (20, 1)):
+        if force_fb not in (None, 108) and vec > force_fb:
+            continue
+        p = ob.params_from_config(1920, 1080, vectors_needed=vec, clusters_needed=clus)
+        s = gpu_scanner_factory(p, force_fb=force_fb)
+        s.set_slices(slices)
+        # cells whose votes are split across slices: sitting at vec-1 / vec / above only in the SUM
+        frames = []
+        for trial in range(12):
+            parts = []
+            for (cx, cy) in [(30, 20), (31, 20), (70, 40), (70, 41)]:
+                n = [vec - 1, vec, vec + 1, 3 * vec + 40][rng.randint(0, 4)]
+                a = np.zeros(max(n, 0), dtype=m.MV_DTYPE)
+                a["dst_x"], a["dst_y"] = 16 * cx + 3, 16 * cy + 5
+                a["src_x"], a["src_y"] = a["dst_x"] - 9, a["dst_y"]
+                parts.append(a)
+            filler = np.zeros(rng.randint(0, 400), dtype=m.MV_DTYPE)      # below threshold
+            filler["dst_x"], filler["dst_y"] = rng.randint(0, 1920, size=len(filler)), rng.randint(0, 1080, size=len(filler))
+            filler["src_x"], filler["src_y"] = filler["dst_x"] + 1, filler["dst_y"]
+            fr = np.concatenate(parts + [filler])
+            frames.append(fr[rng.permutation(len(fr))])               # votes of one cell land in different slices
+        frames += [None, np.zeros(0, dtype=m.MV_DTYPE), frames[0][:3].copy()]
+        b = m.FrameBatch.from_frames(frames)
+        want = assert_scan_parity(s, p, b.mv, b.frame_off, b.has_sd)
+        assert 0 < want.sum() < len(want)
+        mv, off, sd = synth.random_frames(rng, 24, 6000, 1920, 1080, hot=0.6)
+        assert_scan_parity(s, p, mv, off, sd)
+        s.close()
+
+
+def test_scan_frame_slices_big_grids_and_auto(gpu_scanner_factory):
+    import torch
+    # 4K u32 tile, sliced
+    spec = synth.spec_4k(seed=5)
+    spec.events = [synth.Event(1, 6, 100, 60, 4, 3, 9, -5)]
+    mv, off, pts, sd = synth.gen_stream(spec, 8)
+    p = ob.params_from_config(3840, 2160)
+    want = ob.scan_frames(p, mv, off, sd)
+    for S in (0, 1, 4, 8):                                          # 0 = auto (8 frames << 512 slots: slices)
+        s = gpu_scanner_factory(p)
+        s.set_slices(S)
+        assert np.array_equal(s.check_frames(m.FrameBatch(mv, off, None, sd)), want), S
+    # 960x540 grid, 1-bit and 2-bit thermometer tiles, sliced; device-resident entry point
+    specf = synth.spec_4k_fine(seed=9)
+    specf.events = [synth.Event(1, 3, 300, 200, 6, 6, 9, 3), synth.Event(1, 4, 100, 250, 3, 120, 9, 0)]
+    mvf, offf, ptsf, sdf = synth.gen_stream(specf, 4)
+    for vec, fb in ((1, None), (1, 2), (2, None)):
+        pf = ob.params_from_config(3840, 2160, block_size=4, block_shift=2, vectors_needed=vec)
+        wantf = ob.scan_frames(pf, mvf, offf, sdf)
+        for S in (0, 2, 8):
+            s = gpu_scanner_factory(pf, force_fb=fb)
+            s.set_slices(S)
+            got = s.check_frames_device(torch.from_numpy(mvf.view(np.uint8).copy()).cuda(),
+                                        torch.from_numpy(offf.astype(np.int64)).cuda(),
+                                        torch.from_numpy(sdf).cuda())
+            assert np.array_equal(got.cpu().numpy(), wantf), (vec, fb, S)
+    with pytest.raises(m.MtgpuError):
+        s.set_slices(3)
