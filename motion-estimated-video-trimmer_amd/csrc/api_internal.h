@@ -12,7 +12,6 @@ int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 int hip_fail(hipError_t e, const char *what);
 
 int ctx_device(const mtgpu_ctx *c);
-int ctx_bands(const mtgpu_ctx *c);
 // Launch the scan for a device-resident batch on `st`.
 int ctx_launch_scan(mtgpu_ctx *c, const void *d_mv, uint64_t n_records, const uint64_t *d_off,
                     const uint8_t *d_sd, uint32_t n_frames, uint8_t *d_flags, hipStream_t st);

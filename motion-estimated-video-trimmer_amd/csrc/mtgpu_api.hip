@@ -289,7 +289,6 @@ int launch_scan_on(mtgpu_ctx *c, const void *d_mv, uint64_t n_records, const uin
 
 namespace mtgpu {
 int ctx_device(const mtgpu_ctx *c) { return c->device; }
-int ctx_bands(const mtgpu_ctx *c) { return c->k.bands; }
 int ctx_launch_scan(mtgpu_ctx *c, const void *d_mv, uint64_t n_records, const uint64_t *d_off,
                     const uint8_t *d_sd, uint32_t n_frames, uint8_t *d_flags, hipStream_t st) {
   return launch_scan_on(c, d_mv, n_records, d_off, d_sd, n_frames, d_flags, st);
