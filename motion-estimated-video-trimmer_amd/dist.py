@@ -118,3 +118,29 @@ def assemble_stream_lists(gathered, cap: int, streams_per_rank: Sequence[int]) -
             out.append({"rank": r, "local_stream": s, "segments": seg[r, s, :k].copy(),
                         "result": res[r, s].copy()})
     return out
+
+
+def scan_and_merge_timerange(scanner, mv, frame_off, pts, merge_params, has_sd=None, group=None,
+                             job_semantics=True, seg_cap=64):
+    """Time-range sharding of ONE stream, end to end on the devices: this rank scans its own
+    contiguous frame range (device tensors mv / frame_off / pts of that range), the compacted
+    motion timestamps of all ranks are all-gathered, and every rank merges the pooled list once
+    on its GPU.  Bit-identical to scanning the whole stream on one device, because the merge
+    sorts and de-duplicates its input (src/pipeline.cpp:302-304).
+    merge_params: MergeParams of the WHOLE stream.  Returns (segments [k,2] numpy, result record)."""
+    import torch
+    from .scanner import results_from_bytes
+    flags = scanner.check_frames_device(mv, frame_off, has_sd)
+    local_ts = pts[flags.bool()]
+    pooled = gather_timestamps(local_ts, group=group).contiguous()
+    n = pooled.numel()
+    dev = pts.device
+    soff = torch.tensor([0, n], dtype=torch.int64, device=dev)
+    mp = torch.from_numpy(merge_params.to_record().view(np.uint8).copy()).to(dev)
+    if n == 0:
+        pooled = torch.zeros(1, dtype=torch.float64, device=dev)
+    seg, res = scanner.merge_streams_device(None, pooled, soff, mp, job_semantics, seg_cap)
+    torch.cuda.synchronize(dev)
+    rec = results_from_bytes(res.cpu().numpy())[0]
+    k = min(int(rec["n_segments"]), seg_cap)
+    return seg[0, :k].cpu().numpy(), rec

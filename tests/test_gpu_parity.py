@@ -695,3 +695,38 @@ def test_scan_frame_slices_big_grids_and_auto(gpu_scanner_factory):
             assert np.array_equal(got.cpu().numpy(), wantf), (vec, fb, S)
     with pytest.raises(m.MtgpuError):
         s.set_slices(3)
+
+
+def test_timerange_sharded_stream_single_rank_group(gpu_scanner_factory):
+    """dist.scan_and_merge_timerange with a 1-rank NCCL(RCCL) group: scan -> compaction ->
+    all_gather of timestamps -> device merge, against the oracle.  (The 2-rank exchange itself
+    is covered on CPU by tests/test_dist_gloo.py.)"""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    from mvtrim_amd import dist as mdist
+    spec = synth.spec_1080p(seed=41, sub=1)
+    n = 300
+    spec.events = [synth.Event(20, 70, 30, 20, 4, 3, 9, 1), synth.Event(150, 230, 60, 40, 3, 3, -8, 2)]
+    mv, off, pts, sd = synth.gen_stream(spec, n)
+    p = ob.params_from_config(1920, 1080, vectors_needed=1)
+    s = gpu_scanner_factory(p)
+    mp = m.MergeParams(duration=n / 30.0, max_gap_sec=1.0, padding_sec=0.25, min_savings_pct=5.0)
+    want_flags = ob.scan_frames(p, mv, off, sd)
+    want_seg, want_res = ob.pool_and_merge(pts[want_flags != 0], mp, True)
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        seg, rec = mdist.scan_and_merge_timerange(
+            s, torch.from_numpy(mv.view(np.uint8).copy()).cuda(), torch.from_numpy(off.astype(np.int64)).cuda(),
+            torch.from_numpy(pts).cuda(), mp, has_sd=torch.from_numpy(sd).cuda())
+    finally:
+        dist.destroy_process_group()
+    assert int(rec["do_cut"]) == want_res["do_cut"] and int(rec["n_timestamps"]) == want_res["n_timestamps"]
+    assert seg.tobytes() == np.stack([want_seg["start"], want_seg["end"]], 1).tobytes()
+    assert float(rec["time_removed"]) == want_res["time_removed"]
