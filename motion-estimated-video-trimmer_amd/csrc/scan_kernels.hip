@@ -246,24 +246,24 @@ __global__ __launch_bounds__(BLOCK) void scan_frames_kernel(
   __syncthreads();
 
   // ---- slices: publish this partial grid; the LAST workgroup of the frame to arrive sums them
-  // (no workgroup ever waits for another: nothing to deadlock on).  Hand-off = plain stores ->
-  // every wave drains -> barrier -> agent-scope release -> ticket; the last arriver does one
-  // agent-scope acquire before plain loads (cdna_hip_programming.md, Guideline 16).
+  // (no workgroup ever waits for another: nothing to deadlock on).  Hand-off (Guideline 16, R1
+  // in its counter form): 16-byte WRITE-THROUGH (sc1) stores, so no release fence and no L2
+  // write-back -> every storing wave drains -> barrier -> one lane's agent-scope ticket add;
+  // the last arriver does ONE agent-scope acquire (drops this CU's stale L1 lines: the
+  // stream-ordered workspace is reused by later launches), then plain loads.
   if (k.slices > 1) {
     const size_t words = (size_t)k.cnt_words;
     unsigned int *mine = slice_ws + ((size_t)f * (size_t)k.slices + (size_t)slice) * words;
     {
       const u32x4 *c4 = reinterpret_cast<const u32x4 *>(cnt);
-      u32x4 *g4 = reinterpret_cast<u32x4 *>(mine);
-      for (int i = tid; i < (k.cnt_words >> 2); i += BLOCK) g4[i] = c4[i];
+      const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(mine, 0, k.cnt_words * 4, 0x00020000);
+      for (int i = tid; i < (k.cnt_words >> 2); i += BLOCK)
+        __builtin_amdgcn_raw_buffer_store_b128(c4[i], rsrc, i * 16, 0, /*aux: sc1*/ 16);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0)
       *ticket = __hip_atomic_fetch_add(&tickets[f], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
     __syncthreads();
     if (*ticket != (unsigned int)(k.slices - 1)) return;       // not the last: done
     if (tid == 0) {

@@ -730,3 +730,36 @@ def test_timerange_sharded_stream_single_rank_group(gpu_scanner_factory):
     assert int(rec["do_cut"]) == want_res["do_cut"] and int(rec["n_timestamps"]) == want_res["n_timestamps"]
     assert seg.tobytes() == np.stack([want_seg["start"], want_seg["end"]], 1).tobytes()
     assert float(rec["time_removed"]) == want_res["time_removed"]
+
+
+def test_scan_frame_slices_under_load(gpu_scanner_factory):
+    """Slice hand-off under full load with a warm L1 and a reused workspace: thousands of frames
+    x 8 slices keep every CU busy while tiles are published and summed; repeated launches reuse
+    the same stream-ordered workspace addresses, so a missing acquire would read stale tiles.
+    Flags must equal the unsliced kernel's (which equal the oracle's on the tile)."""
+    import torch
+    rng = np.random.RandomState(3)
+    p = ob.params_from_config(1920, 1080, vectors_needed=2, clusters_needed=2)
+    tiles = []
+    for t in range(3):                                        # three different batches, same shapes
+        spec = synth.spec_1080p(seed=50 + t, sub=2)
+        spec.events = synth.scripted_events(spec, 24, seed=t)
+        mv, off, pts, sd = synth.gen_stream(spec, 24)
+        tiles.append((mv, off, ob.scan_frames(p, mv, off, None)))
+    s1 = gpu_scanner_factory(p)
+    s1.set_slices(1)
+    s8 = gpu_scanner_factory(p)
+    s8.set_slices(8)
+    s2 = gpu_scanner_factory(p, force_fb=2)
+    s2.set_slices(4)
+    reps = 80                                                 # 1920 frames, 15 360 workgroups with 8 slices
+    for rnd in range(3):
+        for (mv, off, want) in tiles:
+            d_mv = torch.from_numpy(mv.view(np.uint8).copy()).cuda().repeat(reps)
+            counts = np.tile(np.diff(off.astype(np.int64)), reps)
+            d_off = torch.from_numpy(np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)).cuda()
+            big = np.tile(want, reps)
+            for sc in (s8, s1, s2, s8):
+                got = sc.check_frames_device(d_mv, d_off).cpu().numpy()
+                assert np.array_equal(got, big), (rnd, sc.plan)
+    del rng
