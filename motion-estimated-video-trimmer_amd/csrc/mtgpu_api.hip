@@ -76,6 +76,7 @@ struct mtgpu_ctx {
   int variant = 0;       // MTGPU_VARIANT experiment knob
   int slices_request = 0;  // 0 = auto, else 1/2/4/8 (mtgpu_set_slices, MTGPU_FORCE_SLICES)
   int wide_chunk_rows = 0, wide_lds_bytes = 0;   // single-workgroup-per-CU layout (see make_plan)
+  int item_chunk = 0;    // MTGPU_ITEM_CHUNK (tests): work items per kernel launch, 0 = 2^30
   std::mutex mu;         // guards the staging buffers below
   DevBuf d_mv, d_off, d_sd, d_flags, d_misc;
 };
@@ -212,6 +213,8 @@ int make_plan(mtgpu_ctx *c, int lds_max, int cu_count) {
     c->slices_request = (fs == 1 || fs == 2 || fs == 4 || fs == 8) ? fs : 0;
   }
   k.slices = 1;
+  c->item_chunk = env_int("MTGPU_ITEM_CHUNK", 0);
+  if (c->item_chunk < 0) c->item_chunk = 0;
   c->plan.counter_mode = mode;
   c->plan._pad = 0;
   return MT_OK;
@@ -253,6 +256,7 @@ int launch_scan_on(mtgpu_ctx *c, const void *d_mv, uint64_t n_records, const uin
   L.k.slices = choose_slices(c, n_records, n_frames);
   L.block = c->plan.block_threads;
   L.variant = c->variant;
+  L.item_chunk = (unsigned long long)c->item_chunk;
   L.lds_bytes = c->plan.lds_bytes;
   if (c->wide_lds_bytes > c->plan.lds_bytes &&
       (uint64_t)n_frames * (uint64_t)L.k.bands * (uint64_t)L.k.slices <= (uint64_t)c->plan.cu_count) {

@@ -40,6 +40,7 @@ struct ScanLaunch {
   ScanK k;
   int block;
   int variant;             // experiment knob (MTGPU_VARIANT), 0 = shipped kernel
+  unsigned long long item_chunk;  // work items per launch (0 = 2^30; MTGPU_ITEM_CHUNK shrinks it for tests)
   int lds_bytes;
   hipStream_t stream;
 };

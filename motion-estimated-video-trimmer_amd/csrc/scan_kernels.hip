@@ -367,7 +367,7 @@ static hipError_t launch_one(const ScanLaunch &L) {
   if (e != hipSuccess) return e;
   const unsigned long long items =
       (unsigned long long)L.n_frames * (unsigned long long)L.k.bands * (unsigned long long)L.k.slices;
-  const unsigned long long chunk = 1ull << 30;
+  const unsigned long long chunk = L.item_chunk ? L.item_chunk : (1ull << 30);   // grid.x stays < 2^31
   for (unsigned long long i0 = 0; i0 < items; i0 += chunk) {
     const unsigned int n = (unsigned int)((items - i0 < chunk) ? (items - i0) : chunk);
     hipLaunchKernelGGL(kern, dim3(n), dim3(BLOCK), L.lds_bytes, L.stream, L.mv, L.n_records,

@@ -763,3 +763,28 @@ def test_scan_frame_slices_under_load(gpu_scanner_factory):
                 got = sc.check_frames_device(d_mv, d_off).cpu().numpy()
                 assert np.array_equal(got, big), (rnd, sc.plan)
     del rng
+
+
+def test_scan_launch_chunking(gpu_scanner_factory):
+    """Batches above 2^30 work items are scanned in several launches (grid.x < 2^31); the
+    MTGPU_ITEM_CHUNK knob shrinks the launch size so that the item-offset path is exercised,
+    also together with slices and row bands."""
+    import os
+    rng = np.random.RandomState(77)
+    cases = [(ob.params_from_config(1920, 1080, vectors_needed=1, clusters_needed=1), None, 0),
+             (ob.params_from_config(1920, 1080, vectors_needed=1, clusters_needed=1), None, 4),
+             (ob.params_from_config(3840, 2160, block_size=4, block_shift=2, vectors_needed=1), 32, 0)]   # row bands
+    for p, fb, slices in cases:
+        w = 1920 if p.grid_w == 120 else 3840
+        h = 1080 if p.grid_w == 120 else 2160
+        mv, off, sd = synth.random_frames(rng, 45, 1500, w, h)
+        want = ob.scan_frames(p, mv, off, sd)
+        os.environ["MTGPU_ITEM_CHUNK"] = "7"
+        try:
+            s = gpu_scanner_factory(p, force_fb=fb)
+        finally:
+            del os.environ["MTGPU_ITEM_CHUNK"]
+        if slices:
+            s.set_slices(slices)
+        got = s.check_frames(m.FrameBatch(mv, off, None, sd))
+        assert np.array_equal(got, want), (fb, slices, s.plan)
