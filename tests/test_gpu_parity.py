@@ -174,6 +174,9 @@ EDGE_CFGS = [
     (1920, 1080, dict(block_size=8, block_shift=3)),                                 # 240x135 on 1080p
     (1920, 1080, dict(block_size=16, block_shift=5)),                                # size/shift mismatch
     (640, 480, dict(block_size=1, block_shift=0, vectors_needed=1)),                 # 640x480 cells
+    (32767, 3, dict(block_size=1, block_shift=0, vectors_needed=1, vertical_mask=0.0)),   # widest legal grid
+    (3, 32767, dict(block_size=1, block_shift=0, vectors_needed=1, vertical_mask=0.0)),   # tallest: chunked masks
+    (32767, 40, dict(block_size=1, block_shift=0, vectors_needed=2, clusters_needed=1)),  # wide + row bands
 ]
 
 
