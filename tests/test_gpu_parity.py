@@ -791,3 +791,18 @@ def test_scan_launch_chunking(gpu_scanner_factory):
             s.set_slices(slices)
         got = s.check_frames(m.FrameBatch(mv, off, None, sd))
         assert np.array_equal(got, want), (fb, slices, s.plan)
+
+
+def test_plain_c_example(tmp_path):
+    """examples/scan_example.c: the ABI consumed from plain C (gcc), end to end on the GPU."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.dirname(m.LIB_PATH)
+    exe = str(tmp_path / "scan_example")
+    subprocess.check_call(["gcc", "-std=c11", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "examples", "scan_example.c"), "-o", exe, "-L" + pkg, "-lmtgpu",
+                           "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "motion frames 30, segments 1, do_cut 1" in out.stdout and "[0.500, 2.467]" in out.stdout
