@@ -88,6 +88,10 @@ int mtgpu_get_plan(const mtgpu_ctx *ctx, mtgpu_plan *out);
  * Results never depend on it. */
 int mtgpu_set_slices(mtgpu_ctx *ctx, int slices);
 
+/* Calibration only (bench.py): stream `bytes` of a device buffer with the scan's load flavour
+ * and discard them — the chip's pure-read ceiling on that buffer.  Asynchronous on `stream`. */
+int mtgpu_debug_read_ceiling(mtgpu_ctx *ctx, const void *d_buf, uint64_t bytes, void *stream);
+
 /*
  * check_frame() over a device-resident batch — replaces the per-frame call at
  * src/motion_scanner.cpp:376 (body :217-295).

@@ -72,6 +72,7 @@ ABI = {
     "mtgpu_get_params": (C.c_int, [C.c_void_p, C.POINTER(ScanParamsC)]),
     "mtgpu_get_plan": (C.c_int, [C.c_void_p, C.POINTER(PlanC)]),
     "mtgpu_set_slices": (C.c_int, [C.c_void_p, C.c_int]),
+    "mtgpu_debug_read_ceiling": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
     "mtgpu_scan_frames_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p,
                                            C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     "mtgpu_scan_frames": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

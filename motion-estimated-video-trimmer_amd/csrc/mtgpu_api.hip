@@ -394,6 +394,19 @@ int mtgpu_scan_frames_device(mtgpu_ctx *c, const void *d_mv, uint64_t n_records,
                         static_cast<hipStream_t>(stream));
 }
 
+int mtgpu_debug_read_ceiling(mtgpu_ctx *c, const void *d_buf, uint64_t bytes, void *stream) {
+  if (!c) return fail(MT_ERR_INVALID, "ctx is NULL");
+  if (!d_buf || ((uintptr_t)d_buf & 15u)) return fail(MT_ERR_INVALID, "buffer must be non-NULL and 16-byte aligned");
+  HIP_TRY(hipSetDevice(c->device));
+  std::lock_guard<std::mutex> lock(c->mu);
+  int rc = c->d_sd.reserve(64);                      // 4-byte sink lives in a staging buffer
+  if (rc != MT_OK) return rc;
+  hipError_t e = mtgpu::launch_read_ceiling(d_buf, bytes, static_cast<unsigned int *>(c->d_sd.p), c->plan.cu_count,
+                                            static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return hip_fail(e, "read ceiling launch");
+  return MT_OK;
+}
+
 int mtgpu_set_slices(mtgpu_ctx *c, int slices) {
   if (!c) return fail(MT_ERR_INVALID, "ctx is NULL");
   if (slices != 0 && slices != 1 && slices != 2 && slices != 4 && slices != 8)

@@ -46,5 +46,7 @@ struct ScanLaunch {
 };
 
 hipError_t launch_scan(const ScanLaunch &L);
+hipError_t launch_read_ceiling(const void *p, unsigned long long bytes, unsigned int *sink, int cu_count,
+                               hipStream_t stream);
 
 }  // namespace mtgpu

@@ -357,6 +357,41 @@ __global__ void finalize_flags_kernel(const unsigned long long *__restrict__ fra
   flags[f] = (sd && frame_centres[f] >= clust_need) ? 1 : 0;
 }
 
+// Calibration only: a pure streaming read shaped like the scan (one workgroup per contiguous
+// 1.25 MiB chunk, 512 threads, nt loads, 4 x 16 B in flight per lane, nothing else), folded into
+// a value that is (almost) never stored.  bench.py reports its rate on the scan's own record
+// buffer beside the 8 TB/s spec peak: what a kernel that ONLY reads can reach on this chip.
+constexpr unsigned long long READ_CHUNK16 = (1280ull * 1024ull) / 16ull;
+
+__global__ __launch_bounds__(512) void read_ceiling_kernel(const u32x4 *__restrict__ p, unsigned long long n16,
+                                                           unsigned int *__restrict__ sink) {
+  const unsigned long long b0 = (unsigned long long)blockIdx.x * READ_CHUNK16;
+  const unsigned long long b1 = min(n16, b0 + READ_CHUNK16);
+  unsigned long long i = b0 + threadIdx.x;
+  u32x4 acc = (u32x4){0u, 0u, 0u, 0u};
+  for (; i + 3ull * 512ull < b1; i += 4ull * 512ull) {
+    u32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = __builtin_nontemporal_load(p + i + (unsigned long long)u * 512ull);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc ^= v[u];
+  }
+  for (; i < b1; i += 512ull) acc ^= __builtin_nontemporal_load(p + i);
+  if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9E3779B9u) *sink = acc.x;   // keeps the loads alive
+}
+
+hipError_t launch_read_ceiling(const void *p, unsigned long long bytes, unsigned int *sink, int cu_count,
+                               hipStream_t stream) {
+  (void)cu_count;
+  const unsigned long long n16 = bytes / 16ull;
+  if (n16 == 0) return hipSuccess;
+  const unsigned long long blocks = (n16 + READ_CHUNK16 - 1) / READ_CHUNK16;
+  if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(read_ceiling_kernel, dim3((unsigned int)blocks), dim3(512), 0, stream,
+                     static_cast<const u32x4 *>(p), n16, sink);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ launchers
 
 template <int BLOCK, int FB, int MODE, int UNROLL = 4, int VAR = 0>
