@@ -149,17 +149,27 @@ template <int BLOCK, int UNROLL, int FB, int MODE, int VAR>
 __global__ __launch_bounds__(BLOCK) void scan_frames_kernel(
     const unsigned char *__restrict__ mv, unsigned long long n_records,
     const unsigned long long *__restrict__ frame_off, const unsigned char *__restrict__ has_sd,
-    unsigned int item0, ScanK k, unsigned char *__restrict__ flags,
+    unsigned int item0, unsigned int n_frames, ScanK k, unsigned char *__restrict__ flags,
     unsigned int *__restrict__ frame_centres, unsigned int *slice_ws, unsigned int *tickets) {
   extern __shared__ __attribute__((aligned(16))) unsigned int lds[];
   const int tid = threadIdx.x;
   const unsigned int item = item0 + blockIdx.x;
   // item -> (frame, band) or (frame, slice): bands and slices are never both > 1
-  const unsigned int per_frame = (unsigned int)(k.bands * k.slices);
-  const unsigned int f = item / per_frame;
-  const int sub = (int)(item - f * per_frame);
-  const int band = k.slices > 1 ? 0 : sub;
-  const int slice = k.slices > 1 ? sub : 0;
+  unsigned int f;
+  int band = 0, slice = 0;
+  if (k.bands > 1) {
+    // Bands of one frame re-read the same records: put them on ONE XCD so that the later reader
+    // hits that XCD's L2.  Workgroups b and b+8 share an XCD (round-robin dispatch; speed only,
+    // never correctness): within a group of 8 frames, frame = item % 8, band = (item / 8) % bands.
+    const unsigned int span = 8u * (unsigned int)k.bands;
+    const unsigned int grp = item / span, l = item - grp * span;
+    f = grp * 8u + (l & 7u);
+    band = (int)(l >> 3);
+    if (f >= n_frames) return;
+  } else {
+    f = item / (unsigned int)k.slices;
+    slice = (int)(item - f * (unsigned int)k.slices);
+  }
 
   unsigned long long r0 = frame_off[f], r1 = frame_off[f + 1];
   r1 = r1 < n_records ? r1 : n_records;
@@ -400,14 +410,16 @@ static hipError_t launch_one(const ScanLaunch &L) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, L.lds_bytes);
   if (e != hipSuccess) return e;
+  // bands > 1: frames are dealt in groups of 8 (same-XCD band placement), the last group is padded
   const unsigned long long items =
-      (unsigned long long)L.n_frames * (unsigned long long)L.k.bands * (unsigned long long)L.k.slices;
+      L.k.bands > 1 ? (((unsigned long long)L.n_frames + 7ull) / 8ull) * 8ull * (unsigned long long)L.k.bands
+                    : (unsigned long long)L.n_frames * (unsigned long long)L.k.slices;
   const unsigned long long chunk = L.item_chunk ? L.item_chunk : (1ull << 30);   // grid.x stays < 2^31
   for (unsigned long long i0 = 0; i0 < items; i0 += chunk) {
     const unsigned int n = (unsigned int)((items - i0 < chunk) ? (items - i0) : chunk);
     hipLaunchKernelGGL(kern, dim3(n), dim3(BLOCK), L.lds_bytes, L.stream, L.mv, L.n_records,
-                       L.frame_off, L.has_sd, (unsigned int)i0, L.k, L.flags, L.frame_centres, L.slice_ws,
-                       L.tickets);
+                       L.frame_off, L.has_sd, (unsigned int)i0, L.n_frames, L.k, L.flags, L.frame_centres,
+                       L.slice_ws, L.tickets);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
@@ -428,19 +440,30 @@ static hipError_t launch_variant(const ScanLaunch &L) {
   }
 }
 
+// Row bands re-read a frame's records (once per band): their loads use the default cache policy
+// so that the XCD's L2 keeps the lines for the sibling band (NT = false); everything else
+// streams with the nt hint (-12 % without it on single-pass reads).
+template <int BLOCK, bool NT>
+static hipError_t launch_policy(const ScanLaunch &L) {
+  constexpr int V = NT ? 0 : 4;
+  const int key = L.k.mode * 100 + L.k.fb;
+  switch (key) {
+    case MODE_ADD32 * 100 + 32: return launch_one<BLOCK, 32, MODE_ADD32, 4, V>(L);
+    case MODE_UNARY * 100 + 1: return launch_one<BLOCK, 1, MODE_UNARY, 4, V>(L);
+    case MODE_UNARY * 100 + 2: return launch_one<BLOCK, 2, MODE_UNARY, 4, V>(L);
+    case MODE_UNARY * 100 + 4: return launch_one<BLOCK, 4, MODE_UNARY, 4, V>(L);
+    case MODE_UNARY * 100 + 8: return launch_one<BLOCK, 8, MODE_UNARY, 4, V>(L);
+    case MODE_CAS * 100 + 8: return launch_one<BLOCK, 8, MODE_CAS, 4, V>(L);
+    default: return hipErrorInvalidValue;
+  }
+}
+
 template <int BLOCK>
 static hipError_t launch_block(const ScanLaunch &L) {
   const int key = L.k.mode * 100 + L.k.fb;
   if (key == MODE_ADD32 * 100 + 32 && (L.variant & 15) != 0 && BLOCK != 1024) return launch_variant<BLOCK>(L);
-  switch (key) {
-    case MODE_ADD32 * 100 + 32: return launch_one<BLOCK, 32, MODE_ADD32>(L);
-    case MODE_UNARY * 100 + 1: return launch_one<BLOCK, 1, MODE_UNARY>(L);
-    case MODE_UNARY * 100 + 2: return launch_one<BLOCK, 2, MODE_UNARY>(L);
-    case MODE_UNARY * 100 + 4: return launch_one<BLOCK, 4, MODE_UNARY>(L);
-    case MODE_UNARY * 100 + 8: return launch_one<BLOCK, 8, MODE_UNARY>(L);
-    case MODE_CAS * 100 + 8: return launch_one<BLOCK, 8, MODE_CAS>(L);
-    default: return hipErrorInvalidValue;
-  }
+  if (L.k.bands > 1 && (L.variant & 16) == 0) return launch_policy<BLOCK, false>(L);
+  return launch_policy<BLOCK, true>(L);
 }
 
 hipError_t launch_scan(const ScanLaunch &L) {

@@ -23,6 +23,8 @@ kw = dict(m.config.CODE_DEFAULTS)
 kw.update(gridkw)
 if spec.sub == 1:
     kw["vectors_needed"] = 1
+if os.environ.get("AB_VEC"):
+    kw["vectors_needed"] = int(os.environ["AB_VEC"])
 params = m.ScanParams.from_config(W, H, **kw)
 reps = (frames + distinct - 1) // distinct
 counts = np.tile(np.diff(off.astype(np.int64)), reps)[:frames]
@@ -51,6 +53,7 @@ for r in range(22):
         e0.record(); s.check_frames_device(d_mv, d_off, None, fl); e1.record(); torch.cuda.synchronize()
         if r >= 2:
             times.append(e0.elapsed_time(e1))
+print("plan:", new.plan)
 for name, s, times in variants:
     t = np.array(times)
     print(f"{wl} {frames:5d} {name:6s} median {np.median(t):.4f} ms  min {t.min():.4f}  {alg / np.median(t) / 1e6:7.0f} GB/s")

@@ -46,6 +46,8 @@ def main():
         kw.update(gridkw)
         if spec.sub == 1:
             kw["vectors_needed"] = 1
+        if os.environ.get("AB_VEC"):
+            kw["vectors_needed"] = int(os.environ["AB_VEC"])
         params = m.ScanParams.from_config(W, H, **kw)
         frames = int(os.environ.get("AB_FRAMES", FRAMES[wl]))
         reps = (frames + distinct - 1) // distinct
