@@ -224,7 +224,8 @@ def main():
             "config": {"workload": f"synthetic {a.workload} MV arrays, {params.grid_w}x{params.grid_h} grid, "
                                    f"{a.frames} frames/GPU/step in {S} streams ({a.distinct} distinct frames tiled), "
                                    f"params={a.params}",
-                       "frames_per_gpu": a.frames, "records_per_step_per_gpu": n_records,
+                       "frames_per_gpu": a.frames, "streams_per_gpu": S, "streams_total": S * world,
+                       "records_per_step_per_gpu": n_records,
                        "bytes_per_step_per_gpu": alg_bytes, "parallelism": f"frame-sharded x{world}",
                        "step": "scan kernel" if a.no_merge else "scan + stream-merge kernels" +
                                (" + RCCL all_gather of segment lists" if world > 1 else "")},

@@ -1,0 +1,50 @@
+"""Soak: randomised GPU-vs-oracle parity for MTGPU_SOAK_SECONDS (default 4 s; set it to minutes
+to hunt rare races in the LDS vote / slice hand-off paths).  Every iteration draws a new grid,
+parameter set, counter form, slice count and ragged adversarial batch."""
+import os
+import time
+
+import numpy as np
+import pytest
+
+import mvtrim_amd as m
+from mvtrim_amd import synth
+
+import oracle_binding as ob
+
+pytestmark = pytest.mark.gpu
+
+
+def test_soak_random_parity(gpu_scanner_factory):
+    budget = float(os.environ.get("MTGPU_SOAK_SECONDS", "4"))
+    seed = int(os.environ.get("MTGPU_SOAK_SEED", "12345"))
+    rng = np.random.RandomState(seed)
+    forms = [None, None, 1, 2, 4, 8, 108, 32]
+    t_end = time.time() + budget
+    it = done = 0
+    while time.time() < t_end:
+        it += 1
+        sh = int(rng.randint(2, 6))
+        w, h = int(rng.randint(64, 3900)), int(rng.randint(64, 2200))
+        kw = dict(mv_threshold_sq=float(rng.choice([16.0, 4.0, 0.0, 9.5])), block_size=1 << sh, block_shift=sh,
+                  vectors_needed=int(rng.choice([1, 1, 2, 2, 3, 4, 6, 12, 255])),
+                  clusters_needed=int(rng.choice([1, 2, 2, 3, 10])),
+                  vertical_mask=float(rng.choice([0.0, 0.05, 0.2])))
+        p = ob.params_from_config(w, h, **kw)
+        try:
+            s = gpu_scanner_factory(p, force_fb=forms[it % len(forms)])
+        except m.MtgpuError as e:
+            assert e.code == 2
+            continue
+        s.set_slices(int(rng.choice([0, 1, 2, 4, 8])))
+        n_frames = int(rng.choice([3, 17, 64, 300]))
+        mv, off, sd = synth.random_frames(rng, n_frames, int(rng.choice([200, 3000, 20000])), w, h,
+                                          hot=float(rng.choice([0.05, 0.5, 0.95])))
+        want = ob.scan_frames(p, mv, off, sd, nthreads=8)
+        for _ in range(2):                              # twice: warm caches, reused workspaces
+            got = s.check_frames(m.FrameBatch(mv, off, None, sd))
+            assert np.array_equal(got, want), (seed, it, w, h, kw, s.plan)
+        s.close()
+        done += 1
+    assert done > 0
+    print(f"soak: {done} random configurations checked in {budget:.0f} s")
