@@ -22,8 +22,15 @@ def test_soak_random_parity(gpu_scanner_factory):
     forms = [None, None, 1, 2, 4, 8, 108, 32]
     t_end = time.time() + budget
     it = done = 0
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog_dir = os.path.join(root, "gpurun_out")
+    last_note = time.time()
     while time.time() < t_end:
         it += 1
+        if time.time() - last_note > 30 and os.path.isdir(prog_dir):      # keep long runs visibly alive
+            last_note = time.time()
+            with open(os.path.join(prog_dir, "soak_progress.log"), "a") as fh:
+                fh.write(f"{time.strftime('%H:%M:%S')} seed {seed}: {done} configurations ok\n")
         sh = int(rng.randint(2, 6))
         w, h = int(rng.randint(64, 3900)), int(rng.randint(64, 2200))
         kw = dict(mv_threshold_sq=float(rng.choice([16.0, 4.0, 0.0, 9.5])), block_size=1 << sh, block_shift=sh,
