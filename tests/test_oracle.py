@@ -210,3 +210,42 @@ def test_frame_filter_and_chunks():
     assert ob.chunks(70.0, 30.0) == [(0.0, 30.0, 0), (30.0, 60.0, 1), (60.0, 70.0, 2)]
     assert ob.chunks(60.0, 30.0) == [(0.0, 30.0, 0), (30.0, 60.0, 1)]
     assert ob.chunks(0.0, 30.0) == []
+
+
+# ------------------------------------------------------------------ property-based cross-check
+
+def test_oracle_vs_numpy_model_hypothesis():
+    """hypothesis-driven: arbitrary small frames (any int16 coordinates within the defined
+    domain |dst - src| <= 32767), arbitrary parameters -> the C oracle (early exit) and the
+    numpy model (full count) agree on the flag AND the centre count."""
+    from hypothesis import given, settings, strategies as st
+
+    coord = st.integers(-32768, 32767)
+
+    @st.composite
+    def frames(draw):
+        n = draw(st.integers(0, 60))
+        rows = []
+        for _ in range(n):
+            dx, dy = draw(st.integers(-300, 300)), draw(st.integers(-300, 300))
+            x, y = draw(st.one_of(coord, st.integers(-40, 400))), draw(st.one_of(coord, st.integers(-40, 300)))
+            sx, sy = max(-32768, min(32767, x - dx)), max(-32768, min(32767, y - dy))
+            rows.append((sx, sy, x, y))
+        return rows
+
+    @settings(max_examples=300, deadline=None)
+    @given(frames(), st.integers(8, 360), st.integers(8, 280), st.integers(0, 5),
+           st.sampled_from([0.0, 1.0, 16.0, 16.5, 1e5, float("nan")]), st.integers(0, 6), st.integers(-1, 5),
+           st.sampled_from([0.0, 0.05, 0.2, 0.5]), st.booleans())
+    def check(rows, w, h, shift, thr, vec, clus, mask, has_sd):
+        p = ob.params_from_config(w, h, mv_threshold_sq=thr, block_size=1 << shift, block_shift=shift,
+                                  vectors_needed=vec, clusters_needed=clus, vertical_mask=mask)
+        mv = np.zeros(len(rows), dtype=m.MV_DTYPE)
+        if rows:
+            a = np.array(rows, dtype=np.int64)
+            mv["src_x"], mv["src_y"], mv["dst_x"], mv["dst_y"] = a[:, 0], a[:, 1], a[:, 2], a[:, 3]
+        flag, centres, _ = ob.check_frame(p, mv, has_sd, count_centres=True)
+        assert (flag, centres) == check_frame_np(p, mv, has_sd)
+        assert ob.check_frame(p, mv, has_sd) == flag
+
+    check()
