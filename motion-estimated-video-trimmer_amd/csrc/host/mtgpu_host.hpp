@@ -184,10 +184,48 @@ class MtmvSource : public FrameSource {
 };
 
 // ---------------------------------------------------------------- scanner
+// The GPU side of one worker: a scan context (cfg + launch plan) and its pinned pipe.  Kept
+// separate from the decoder-facing scanner so that a batch worker can reuse it for the next
+// video of the same size instead of re-pinning staging memory per file.
+class GpuBackend {
+  mtgpu_ctx *ctx_ = nullptr;
+  mtgpu_pipe *pipe_ = nullptr;
+  int width_ = -1, height_ = -1, device_ = -1;
+ public:
+  GpuBackend() = default;
+  ~GpuBackend() { reset(); }
+  GpuBackend(const GpuBackend &) = delete;
+  GpuBackend &operator=(const GpuBackend &) = delete;
+  void reset() {
+    if (pipe_) mtgpu_pipe_destroy(pipe_);
+    if (ctx_) mtgpu_destroy(ctx_);
+    pipe_ = nullptr; ctx_ = nullptr; width_ = height_ = device_ = -1;
+  }
+  mtgpu_ctx *ctx() { return ctx_; }
+  mtgpu_pipe *pipe() { return pipe_; }
+  // cfg/grid derivation of MotionScanner::initialize (motion_scanner.cpp:184-199) + device setup;
+  // a backend already set up for this frame size and device is reused as it is.
+  bool ensure(int width, int height, int device, uint64_t batch_records, uint32_t batch_frames, int n_buffers,
+              std::string &err) {
+    if (ctx_ && pipe_ && width == width_ && height == height_ && device == device_) return true;
+    reset();
+    mt_scan_params p;
+    int rc = mtgpu_params_from_config(&p, width, height, Config::mv_threshold_sq(), Config::block_size(),
+                                      Config::block_shift(), Config::vectors_needed(), Config::clusters_needed(),
+                                      Config::vertical_mask());
+    if (rc == MT_OK) rc = mtgpu_create(&p, device, &ctx_);
+    if (rc == MT_OK) rc = mtgpu_pipe_create(ctx_, batch_records, batch_frames, n_buffers, &pipe_);
+    if (rc != MT_OK) { err = mtgpu_last_error(); reset(); return false; }
+    width_ = width; height_ = height; device_ = device;
+    return true;
+  }
+};
+
 class GpuMotionScanner {   // public shape of MotionScanner (motion_scanner.hpp:113-152)
   FrameSource &src_;
   int device_;
-  mtgpu_ctx *ctx_ = nullptr;
+  GpuBackend own_;
+  GpuBackend *be_;           // own_ or a backend shared across the videos of one batch worker
   mtgpu_pipe *pipe_ = nullptr;
   mtgpu_batch *cur_ = nullptr;
   int inflight_ = 0;
@@ -227,21 +265,23 @@ class GpuMotionScanner {   // public shape of MotionScanner (motion_scanner.hpp:
   }
 
  public:
-  GpuMotionScanner(FrameSource &src, int device) : src_(src), device_(device) {}
-  ~GpuMotionScanner() { if (pipe_) mtgpu_pipe_destroy(pipe_); if (ctx_) mtgpu_destroy(ctx_); }
+  GpuMotionScanner(FrameSource &src, int device, GpuBackend *shared = nullptr)
+      : src_(src), device_(device), be_(shared ? shared : &own_) {}
+  ~GpuMotionScanner() {      // leave a shared pipe idle: nothing in flight, nothing half-filled
+    if (!pipe_) return;
+    std::vector<double> sink;
+    while (inflight_ > 0 && collect_one(sink)) {}
+    if (cur_) { mtgpu_pipe_release(pipe_, cur_); cur_ = nullptr; }
+  }
   GpuMotionScanner(const GpuMotionScanner &) = delete;
   GpuMotionScanner &operator=(const GpuMotionScanner &) = delete;
   const std::string &error() const { return err_; }
-  mtgpu_ctx *context() { return ctx_; }
+  mtgpu_ctx *context() { return be_->ctx(); }
 
-  // cfg/grid derivation of MotionScanner::initialize (motion_scanner.cpp:184-199) + device setup
-  bool initialize(uint64_t batch_records = 1u << 18, uint32_t batch_frames = 256, int n_buffers = 3) {
-    mt_scan_params p;
-    if (!ok(mtgpu_params_from_config(&p, src_.width(), src_.height(), Config::mv_threshold_sq(),
-                                     Config::block_size(), Config::block_shift(), Config::vectors_needed(),
-                                     Config::clusters_needed(), Config::vertical_mask()))) return false;
-    if (!ok(mtgpu_create(&p, device_, &ctx_))) return false;
-    return ok(mtgpu_pipe_create(ctx_, batch_records, batch_frames, n_buffers, &pipe_));
+  bool initialize(uint64_t batch_records = 1u << 17, uint32_t batch_frames = 256, int n_buffers = 3) {
+    if (!be_->ensure(src_.width(), src_.height(), device_, batch_records, batch_frames, n_buffers, err_)) return false;
+    pipe_ = be_->pipe();
+    return true;
   }
   double get_duration() { return src_.duration(); }
   double get_fps() { return src_.fps(); }
@@ -302,8 +342,10 @@ struct PipelineResult {
 // own source + GpuMotionScanner, worker i on device i % n_devices), pool, merge on the GPU.
 // `make_source` is called once per worker (+ once for the probe), like the per-thread
 // MotionScanner(file_buffer) of pipeline.cpp:197.
+// `pool` (optional, >= num_threads entries) lends each worker a GpuBackend that outlives this call.
 template <class MakeSource>
-int run_scan_pipeline(MakeSource make_source, int num_threads, PipelineResult &out, int device_base = 0) {
+int run_scan_pipeline(MakeSource make_source, int num_threads, PipelineResult &out, int device_base = 0,
+                      std::vector<std::unique_ptr<GpuBackend>> *pool = nullptr) {
   std::unique_ptr<FrameSource> probe = make_source();                    // pipeline.cpp:110-120
   const double duration = probe->duration();
   const double chunk = Config::chunk_duration_sec();
@@ -328,7 +370,8 @@ int run_scan_pipeline(MakeSource make_source, int num_threads, PipelineResult &o
     workers.emplace_back([&, i] {                                        // :186-235
       const auto i0 = std::chrono::high_resolution_clock::now();
       sources[i] = make_source();
-      scanners[i] = std::make_unique<GpuMotionScanner>(*sources[i], (device_base + i) % n_dev);
+      GpuBackend *shared = (pool && (size_t)i < pool->size()) ? (*pool)[i].get() : nullptr;
+      scanners[i] = std::make_unique<GpuMotionScanner>(*sources[i], (device_base + i) % n_dev, shared);
       if (!scanners[i]->initialize()) {                                  // :198-199 (here: reported)
         std::lock_guard<std::mutex> l(err_mu);
         out.error = scanners[i]->error();
@@ -410,6 +453,9 @@ int process_batch(const std::vector<std::string> &files, const std::string &outp
   std::vector<std::thread> streams;
   for (int s = 0; s < parallel_streams; ++s) {
     streams.emplace_back([&, s] {
+      // this stream's workers keep their GPU contexts + pinned pipes from one video to the next
+      std::vector<std::unique_ptr<GpuBackend>> pool;
+      for (int i = 0; i < threads_per_stream; ++i) pool.emplace_back(new GpuBackend());
       for (;;) {
         size_t idx;
         { std::lock_guard<std::mutex> l(q_mu); if (next >= files.size()) return; idx = next++; }   // get_next_file
@@ -422,7 +468,7 @@ int process_batch(const std::vector<std::string> &files, const std::string &outp
         int rc = 1;
         try {
           auto factory = open_source(in);
-          rc = run_scan_pipeline(factory, threads_per_stream, job.result, s * threads_per_stream);
+          rc = run_scan_pipeline(factory, threads_per_stream, job.result, s * threads_per_stream, &pool);
         } catch (const std::exception &e) {
           job.result.error = e.what();
         }
