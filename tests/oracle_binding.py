@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ORACLE_LIB = os.path.join(ROOT, "oracle", "libmt_oracle.so")
+ORACLE_LIB = os.environ.get("MT_ORACLE_LIB", os.path.join(ROOT, "oracle", "libmt_oracle.so"))   # override: sanitizer builds
 
 import mvtrim_amd as m  # noqa: E402  (record dtypes only)
 from mvtrim_amd._abi import MergeParamsC, MergeResultC, ScanParamsC  # noqa: E402
