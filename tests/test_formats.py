@@ -104,3 +104,28 @@ def test_mtmv_roundtrip(tmp_path):
         if a is not None:
             assert a.tobytes() == np.asarray(b).tobytes()
     assert os.path.getsize(path) == 56 + 24 * 12 + 40 * int(hdr["n_records"])
+
+
+def test_formats_feed_the_scan_identically(tmp_path):
+    """Frames that went through the .mtmv container, and through the extract_mvs JSON (whose
+    int16 src fields are rebuilt as dst + trunc(motion/scale)), give the oracle the same flags as
+    the original records."""
+    spec = synth.StreamSpec(width=640, height=480, block=16, sub=2, fps=25.0, gop=10, seed=31)
+    spec.events = [synth.Event(2, 14, 10, 8, 4, 3, 9, -4), synth.Event(20, 28, 25, 15, 3, 3, -7, 2)]
+    n = 30
+    frames = [synth.gen_frame(spec, i) for i in range(n)]
+    pts = [spec.pts_seconds(i) for i in range(n)]
+    p = ob.params_from_config(640, 480)
+    b0 = m.FrameBatch.from_frames(frames)
+    want = ob.scan_frames(p, b0.mv, b0.frame_off, b0.has_sd)
+    assert 0 < want.sum() < n
+    mt = str(tmp_path / "s.mtmv")
+    m.mvfile.write_mtmv(mt, 640, 480, 1, 90000, 25.0, n / 25.0, [spec.pts_ticks(i) for i in range(n)], frames)
+    _, tab, mv = m.mvfile.read_mtmv(mt)
+    b1 = m.FrameBatch.from_frames(m.mvfile.frames_of(tab, mv))
+    assert np.array_equal(ob.scan_frames(p, b1.mv, b1.frame_off, b1.has_sd), want)
+    js = str(tmp_path / "s.json")
+    m.mvjson.write_json(js, frames, pts, (1, 90000))
+    f2, _, _ = m.mvjson.read_json(js)
+    b2 = m.FrameBatch.from_frames(f2)
+    assert np.array_equal(ob.scan_frames(p, b2.mv, b2.frame_off, b2.has_sd), want)
