@@ -9,13 +9,21 @@ A step = one pass of the hot path over one device-resident batch of synthetic
 Inputs are resident in HBM before the timed region.  Frames shard across ranks
 (weak scaling: every rank owns `--frames` frames of its own streams).
 
+Launching: `python bench.py --gpus N` starts N rank processes itself (one per GPU, RCCL
+rendezvous on 127.0.0.1) when it is not already running under a launcher; under
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` it is one rank
+(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment).
+
 Prints ONE JSON line on rank 0 (contract in the task statement), including
-  roofline     — the scan kernel: algorithmic bytes / live HIP-event duration vs 8 TB/s
-  cpu_baseline — the C oracle timed on this host's cores on a bounded sample (N=1 only)
+  roofline        — the scan kernel: algorithmic bytes / live HIP-event duration vs 8 TB/s
+  cpu_baseline    — the C oracle timed on this host's cores on a bounded sample (N=1 only)
+  other_workloads — (N=1 only) 4K 240x135 and 4K fine 960x540 scans, same measurement
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,8 +35,14 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s measured copy)
 
+# (workload, params, frames, steps): scanned after the headline at N=1 and reported under
+# "other_workloads" (north_star: frames/s on 1080p AND 4K; config 5 = the 960x540 fine grid).
+OTHER_WORKLOADS = [("4k_dense8x8", "code_defaults", 1024, 40),
+                   ("4k_fine", "code_defaults", 1024, 12),
+                   ("4k_fine", "shipped_env", 512, 12)]
 
-def parse():
+
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -41,11 +55,67 @@ def parse():
     ap.add_argument("--params", default="code_defaults", choices=["code_defaults", "shipped_env"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample budget (0 = skip)")
     ap.add_argument("--no-merge", action="store_true", help="time the scan kernel alone")
+    ap.add_argument("--no-others", action="store_true", help="skip the other_workloads leg")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --same-device rehearses the N>1 control flow on a 1-GPU box")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
+
+# ---------------------------------------------------------------------------- launcher
+
+def needs_launch(a, environ):
+    """True when this process must start the ranks itself: more than one GPU asked for and no
+    launcher (torchrun / the driver) has already made it a rank."""
+    return a.gpus > 1 and "WORLD_SIZE" not in environ and "RANK" not in environ
+
+
+def rank_environments(n, environ, port):
+    """One environment per rank for a single-node run (rendezvous on 127.0.0.1)."""
+    envs = []
+    for r in range(n):
+        e = dict(environ)
+        e.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                 MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool (RCCL needs it)
+        envs.append(e)
+    return envs
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(a, argv, environ=None, popen=subprocess.Popen):
+    """Start a.gpus fresh rank processes of this script (the parent never touches HIP, and no
+    process that has is ever re-exec'ed), wait for all of them; rank 0's stdout (the JSON line)
+    is ours.  Returns the exit code: non-zero if any rank failed."""
+    environ = dict(os.environ if environ is None else environ)
+    envs = rank_environments(a.gpus, environ, free_port())
+    cmd = [sys.executable, os.path.abspath(__file__)] + list(argv)
+    procs = [popen(cmd, env=e, stdout=None if r == 0 else subprocess.DEVNULL) for r, e in enumerate(envs)]
+    rc = 0
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            code = p.poll()
+            if code is None:
+                continue
+            pending.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in pending:                 # a rank died: the others would wait forever in a collective
+                    q.terminate()
+        if pending:
+            time.sleep(0.05)
+    return rc
+
+
+# ---------------------------------------------------------------------------- workloads
 
 def make_spec(workload, seed):
     from mvtrim_amd import synth
@@ -58,8 +128,88 @@ def make_spec(workload, seed):
     return synth.spec_4k_fine(seed=seed), (3840, 2160, dict(block_size=4, block_shift=2))
 
 
-def main():
-    a = parse()
+def build_workload(workload, params_name, frames, distinct, seed, dev):
+    """`distinct` generated frames tiled to `frames`, resident on `dev`."""
+    import torch
+    import mvtrim_amd as m
+    from mvtrim_amd import synth
+    spec, (W, H, gridkw) = make_spec(workload, seed=seed)
+    spec.events = synth.scripted_events(spec, distinct)
+    mv, off, pts, sd = synth.gen_stream(spec, distinct)
+    kw = dict(m.config.CODE_DEFAULTS if params_name == "code_defaults" else m.config.SHIPPED_ENV)
+    kw.update(gridkw)
+    if spec.sub == 1 and params_name == "code_defaults":
+        kw["vectors_needed"] = 1      # one record per cell can never collect 2 votes in a cell
+    params = m.ScanParams.from_config(W, H, **kw)
+    scanner = m.MotionScanner(params, device=dev.index)
+    reps = (frames + distinct - 1) // distinct
+    counts = np.tile(np.diff(off.astype(np.int64)), reps)[:frames]
+    off_big = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    d_tile = torch.from_numpy(mv.view(np.uint8).copy()).to(dev)
+    d_mv = d_tile.repeat(reps)[: int(off_big[-1]) * 40].contiguous()
+    del d_tile
+    n_records = int(off_big[-1])
+    return dict(spec=spec, mv=mv, off=off, params=params, scanner=scanner, reps=reps, d_mv=d_mv,
+                d_off=torch.from_numpy(off_big).to(dev), n_records=n_records, frames=frames, distinct=distinct,
+                d_flags=torch.empty(frames, dtype=torch.uint8, device=dev),
+                alg_bytes=40 * n_records + 9 * frames)   # SURVEY §8d: 40*N_mv + 8 (offset) + 1 (flag) per frame
+
+
+def time_scan_only(w, steps, warmup=3):
+    """Scan kernel alone, HIP events on the launch stream (torch's current stream is passed to the
+    C ABI explicitly).  Returns mean kernel ms."""
+    import torch
+    s = w["scanner"]
+    for _ in range(warmup):
+        s.check_frames_device(w["d_mv"], w["d_off"], None, w["d_flags"])
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    for e0, e1 in ev:
+        e0.record()
+        s.check_frames_device(w["d_mv"], w["d_off"], None, w["d_flags"])
+        e1.record()
+    torch.cuda.synchronize()
+    return float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))
+
+
+def roofline_of(alg_bytes, kern_ms):
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "scan_frames_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "kernel_ms": kern_ms,
+            "algorithmic_bytes_per_launch": alg_bytes}
+
+
+def other_workloads(dev, distinct):
+    """4K / fine-grid scans after the headline (N=1): frames/s, kernel ms, roofline fraction; every
+    batch's flags are checked to be the tile's flags repeated and the tile's flags == the oracle's."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_binding as ob     # checker only
+    out = []
+    for (wl, pn, frames, steps) in OTHER_WORKLOADS:
+        dd = min(distinct, 30)
+        w = build_workload(wl, pn, frames, dd, 1000, dev)
+        kern_ms = time_scan_only(w, steps)
+        flags = w["d_flags"].cpu().numpy()
+        tile = flags[:dd]
+        assert np.array_equal(flags, np.tile(tile, w["reps"])[:frames]), f"{wl}: flags are not tile-periodic"
+        want = ob.scan_frames(w["params"], w["mv"], w["off"], None, nthreads=min(len(os.sched_getaffinity(0)), 16))
+        assert np.array_equal(tile, want), f"{wl}: GPU flags differ from the oracle"
+        r = roofline_of(w["alg_bytes"], kern_ms)
+        p = w["params"]
+        out.append({"workload": f"synthetic {wl} MV arrays, {p.grid_w}x{p.grid_h} grid, {frames} frames "
+                                f"({dd} distinct tiled), params={pn}",
+                    "frames_per_s": frames / (kern_ms * 1e-3), "kernel_ms": kern_ms, "steps": steps,
+                    "achieved_GBps": r["achieved"], "frac": r["frac"], "plan": w["scanner"].plan,
+                    "motion_frames_in_batch": int(flags.sum())})
+        w["scanner"].close()
+        del w
+        torch.cuda.empty_cache()
+    return out
+
+
+# ---------------------------------------------------------------------------- one rank
+
+def run_rank(a):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -67,7 +217,6 @@ def main():
     import torch.distributed as dist
     import mvtrim_amd as m
     from mvtrim_amd import dist as mdist
-    from mvtrim_amd import synth
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
@@ -82,26 +231,10 @@ def main():
             dist.init_process_group("gloo")
 
     # ---------------- synthetic input: `distinct` generated frames, tiled to `frames`
-    spec, (W, H, gridkw) = make_spec(a.workload, seed=1000 + rank)
-    spec.events = synth.scripted_events(spec, a.distinct)
-    mv, off, pts, sd = synth.gen_stream(spec, a.distinct)
-    kw = dict(m.config.CODE_DEFAULTS if a.params == "code_defaults" else m.config.SHIPPED_ENV)
-    kw.update(gridkw)
-    if spec.sub == 1:
-        kw["vectors_needed"] = 1      # one record per cell can never collect 2 votes in a cell
-    params = m.ScanParams.from_config(W, H, **kw)
-    scanner = m.MotionScanner(params, device=local)
-
-    reps = (a.frames + a.distinct - 1) // a.distinct
-    counts = np.tile(np.diff(off.astype(np.int64)), reps)[: a.frames]
-    off_big = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
-    d_tile = torch.from_numpy(mv.view(np.uint8).copy()).to(dev)
-    d_mv = d_tile.repeat(reps)[: int(off_big[-1]) * 40].contiguous()
-    del d_tile
-    d_off = torch.from_numpy(off_big).to(dev)
-    d_flags = torch.empty(a.frames, dtype=torch.uint8, device=dev)
-    n_records = int(off_big[-1])
-    alg_bytes = 40 * n_records + 9 * a.frames          # 40*N_mv + 8 (offset) + 1 (flag) per frame
+    w = build_workload(a.workload, a.params, a.frames, a.distinct, 1000 + rank, dev)
+    spec, mv, off, params, scanner = w["spec"], w["mv"], w["off"], w["params"], w["scanner"]
+    d_mv, d_off, d_flags, n_records, alg_bytes, reps = (w["d_mv"], w["d_off"], w["d_flags"], w["n_records"],
+                                                         w["alg_bytes"], w["reps"])
 
     # streams: frames split evenly; pts restart per stream at 30 fps
     S = max(1, min(a.streams, a.frames))
@@ -199,7 +332,6 @@ def main():
     if rank == 0:
         total_frames = a.frames * world * a.steps
         value = total_frames / dt
-        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         traffic = None
         tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # HBM bytes/launch from a --pmc run, if committed
         if os.path.exists(tp):
@@ -209,12 +341,20 @@ def main():
             except Exception:
                 traffic = None
         cpu = None
+        others = None
         # the batch is the generated tile repeated: so must be its flags (checks every frame of the
         # 5 GB batch, not only the first tile, against the oracle-verified tile flags below)
         tile_flags = flags_host[: a.distinct]
         assert np.array_equal(flags_host, np.tile(tile_flags, reps)[: a.frames]), "flags are not tile-periodic"
         if world == 1 and a.cpu_seconds > 0:
             cpu = cpu_baseline(params, mv, off, tile_flags, a.cpu_seconds, a.workload)
+        if world == 1 and not a.no_others:
+            del d_mv, d_off, w
+            torch.cuda.empty_cache()
+            others = other_workloads(dev, a.distinct)
+        roof = roofline_of(alg_bytes, kern_ms)
+        roof.update({"traffic": traffic, "measured_read_ceiling": read_ceiling,
+                     "frac_of_measured_ceiling": roof["achieved"] / read_ceiling})
         line = {
             "metric": "MV-scan frames/sec at 1080p grid" if a.workload.startswith("1080p") else "MV-scan frames/sec",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -229,11 +369,9 @@ def main():
                        "bytes_per_step_per_gpu": alg_bytes, "parallelism": f"frame-sharded x{world}",
                        "step": "scan kernel" if a.no_merge else "scan + stream-merge kernels" +
                                (" + RCCL all_gather of segment lists" if world > 1 else "")},
-            "roofline": {"bound": "hbm", "kernel": "scan_frames_kernel", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes,
-                         "measured_read_ceiling": read_ceiling, "frac_of_measured_ceiling": achieved / read_ceiling},
+            "roofline": roof,
             "cpu_baseline": cpu,
+            "other_workloads": others,
             "motion_frames_in_batch": int(flags_host.sum()),
         }
         print(json.dumps(line), flush=True)
@@ -244,14 +382,28 @@ def main():
     del out
 
 
+def host_cpu_info():
+    model = "unknown"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return model, os.cpu_count(), len(os.sched_getaffinity(0))
+
+
 def cpu_baseline(params, mv, off, gpu_flags, budget_s, workload):
     """The C oracle (kind "port": our restatement of the reference's check_frame) timed on
     this host's cores on a bounded sample: the `distinct` generated frames, scanned
-    repeatedly until ~budget_s seconds of wall time; frames split over all usable cores
-    (one private grid per thread, the reference's one-scanner-per-worker model)."""
+    repeatedly until ~budget_s seconds of wall time; frames split over the usable cores, capped
+    at 16 = a 1-GPU box's CPU share (one private grid per thread, the reference's
+    one-scanner-per-worker model)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_binding as ob     # checker / baseline only
-    cores = min(len(os.sched_getaffinity(0)), 16)     # a 1-GPU box's CPU share is 16 cores
+    model, cores_total, cores_usable = host_cpu_info()
+    cores = min(cores_usable, 16)
     n0 = len(off) - 1
     flags = ob.scan_frames(params, mv, off, None, nthreads=cores)       # warm-up + parity check
     assert np.array_equal(flags, gpu_flags), "GPU flags differ from the oracle on the bench tile"
@@ -275,7 +427,16 @@ def cpu_baseline(params, mv, off, gpu_flags, budget_s, workload):
     return {"value": n * reps / t_mt, "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"{n} {workload} frames ({n0} distinct, {mv.nbytes / 1e6:.0f} MB) x {reps} passes "
                       f"({t_mt:.1f} s wall), oracle/mt_oracle.c scan, {cores} pthreads",
-            "value_1core": n / t1}
+            "value_1core": n / t1, "host_cpu": model, "host_cores_total": cores_total,
+            "host_cores_usable": cores_usable}
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    a = parse(argv)
+    if needs_launch(a, os.environ):
+        sys.exit(launch_ranks(a, argv))
+    run_rank(a)
 
 
 if __name__ == "__main__":

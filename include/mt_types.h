@@ -40,13 +40,26 @@ typedef struct mt_mv {
 
 #define MT_MV_BYTES 40
 
+/*
+ * Compact record: the 8 bytes of an AVMotionVector that check_frame reads (src_x, src_y,
+ * dst_x, dst_y = bytes 6..13; src/motion_scanner.cpp:246-256), packed back to back.  What the
+ * host dispatcher stages and ships over PCIe instead of the 40-byte record (5x fewer bytes).
+ */
+typedef struct mt_mv_compact {
+  int16_t src_x, src_y;
+  int16_t dst_x, dst_y;
+} mt_mv_compact;
+#define MT_COMPACT_BYTES 8
+
 #if defined(__cplusplus)
 static_assert(sizeof(mt_mv) == MT_MV_BYTES, "mt_mv must match AVMotionVector (40 B)");
 static_assert(offsetof(mt_mv, src_x) == 6 && offsetof(mt_mv, src_y) == 8, "mt_mv layout");
 static_assert(offsetof(mt_mv, dst_x) == 10 && offsetof(mt_mv, dst_y) == 12, "mt_mv layout");
 static_assert(offsetof(mt_mv, flags) == 16 && offsetof(mt_mv, motion_x) == 24, "mt_mv layout");
 static_assert(offsetof(mt_mv, motion_scale) == 32, "mt_mv layout");
+static_assert(sizeof(mt_mv_compact) == 8, "mt_mv_compact is bytes 6..13 of mt_mv");
 #else
+_Static_assert(sizeof(mt_mv_compact) == 8, "mt_mv_compact is bytes 6..13 of mt_mv");
 _Static_assert(sizeof(mt_mv) == MT_MV_BYTES, "mt_mv must match AVMotionVector (40 B)");
 _Static_assert(offsetof(mt_mv, src_x) == 6 && offsetof(mt_mv, dst_y) == 12, "mt_mv layout");
 _Static_assert(offsetof(mt_mv, flags) == 16 && offsetof(mt_mv, motion_scale) == 32, "mt_mv layout");

@@ -107,6 +107,21 @@ int mtgpu_scan_frames_device(mtgpu_ctx *ctx, const void *d_mv, uint64_t n_record
                              const uint64_t *d_frame_off, const uint8_t *d_has_sd,
                              uint32_t n_frames, uint8_t *d_flags, void *stream);
 
+/*
+ * The same scan over COMPACT records (mt_mv_compact: bytes 6..13 of each AVMotionVector, the
+ * only bytes check_frame reads, src/motion_scanner.cpp:246-256), 8 bytes each, device-resident
+ * and 8-byte aligned.  This is what the host dispatcher below stages and ships over PCIe; a
+ * host that packs its own batches (mtgpu_pack_records) can call it directly.  Same results as
+ * mtgpu_scan_frames_device on the records the compact form was packed from.
+ */
+int mtgpu_scan_frames_device_compact(mtgpu_ctx *ctx, const void *d_rec8, uint64_t n_records,
+                                     const uint64_t *d_frame_off, const uint8_t *d_has_sd,
+                                     uint32_t n_frames, uint8_t *d_flags, void *stream);
+
+/* Host helper (data movement only, no result is computed): copy bytes 6..13 of each of
+ * n_records 40-byte AVMotionVector records at `mv_bytes` into 8-byte compact records at `out8`. */
+int mtgpu_pack_records(const void *mv_bytes, uint64_t n_records, void *out8);
+
 /* Same for HOST pointers: validates frame_off, copies the batch to the device,
  * scans, copies the flags back, synchronous.  This is the call an adapter makes
  * after copying each AVFrame's side data into a batch. */
@@ -166,6 +181,13 @@ typedef struct mtgpu_batch mtgpu_batch;
 
 int mtgpu_pipe_create(mtgpu_ctx *ctx, uint64_t max_records_per_batch, uint32_t max_frames_per_batch,
                       int n_buffers, mtgpu_pipe **out);
+/* Staging layout of a pipe.  COMPACT8 (what mtgpu_pipe_create picks): add_frame copies only the
+ * 8 bytes per record that the scan reads into pinned memory, so 5x fewer bytes cross PCIe and
+ * HBM; AOS40: the 40-byte records are staged unchanged.  Results are identical. */
+#define MT_LAYOUT_COMPACT8 0
+#define MT_LAYOUT_AOS40 1
+int mtgpu_pipe_create_layout(mtgpu_ctx *ctx, uint64_t max_records_per_batch, uint32_t max_frames_per_batch,
+                             int n_buffers, int layout, mtgpu_pipe **out);
 void mtgpu_pipe_destroy(mtgpu_pipe *pipe);
 
 /* A free staging batch to fill, or MT_ERR_BUSY if all are in flight / held. */
@@ -174,16 +196,21 @@ int mtgpu_pipe_acquire(mtgpu_pipe *pipe, mtgpu_batch **out);
 /* Append one decoded frame: copies n_bytes / 40 records (trailing bytes ignored, :226).
  * mv_bytes == NULL with has_side_data == 0 records a frame without MV side data (:219-221).
  * `tag` is carried through untouched (e.g. a frame index).  MT_ERR_CAPACITY if the frame
- * does not fit the batch: submit this batch and add the frame to the next one. */
+ * does not fit the batch: submit this batch and add the frame to the next one.  A single frame
+ * with more records than a whole batch is accepted (check_frame takes any count): an EMPTY
+ * batch grows its staging to hold it. */
 int mtgpu_batch_add_frame(mtgpu_batch *batch, const void *mv_bytes, uint64_t n_bytes,
                           int has_side_data, double pts, uint64_t tag);
 uint32_t mtgpu_batch_frames(const mtgpu_batch *batch);
 
-/* Asynchronous: H2D copy + scan + flags D2H on the batch's stream.  Empty batches are legal. */
+/* Asynchronous: H2D copy + scan + flags D2H on the batch's stream.  Empty batches are legal.
+ * On failure nothing of the batch is left in flight and it is still being filled (retry the
+ * submit, or release it). */
 int mtgpu_pipe_submit(mtgpu_pipe *pipe, mtgpu_batch *batch);
 
 /* Block until the OLDEST submitted batch is done and expose its results (host pointers valid
- * until mtgpu_pipe_release).  MT_ERR_INVALID if nothing is in flight. */
+ * until mtgpu_pipe_release).  MT_ERR_INVALID if nothing is in flight.  If waiting fails, *out
+ * is still set so that the batch can be released. */
 int mtgpu_pipe_collect(mtgpu_pipe *pipe, mtgpu_batch **out, const uint8_t **flags,
                        const double **pts, const uint64_t **tags, uint32_t *n_frames);
 int mtgpu_pipe_release(mtgpu_pipe *pipe, mtgpu_batch *batch);

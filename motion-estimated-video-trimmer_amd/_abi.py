@@ -13,6 +13,8 @@ import numpy as np
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "libmtgpu.so")
 
+LAYOUT_COMPACT8, LAYOUT_AOS40 = 0, 1
+COMPACT_DTYPE = np.dtype([("src_x", "<i2"), ("src_y", "<i2"), ("dst_x", "<i2"), ("dst_y", "<i2")])
 MT_OK, MT_ERR_INVALID, MT_ERR_CAPACITY, MT_ERR_DEVICE, MT_ERR_NOMEM, MT_ERR_BUSY = 0, 1, 2, 3, 4, 5
 
 # AVMotionVector-compatible record (include/mt_types.h: mt_mv; 40 bytes).
@@ -75,6 +77,9 @@ ABI = {
     "mtgpu_debug_read_ceiling": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
     "mtgpu_scan_frames_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p,
                                            C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "mtgpu_scan_frames_device_compact": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p,
+                                                   C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "mtgpu_pack_records": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p]),
     "mtgpu_scan_frames": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_uint32, C.c_void_p]),
     "mtgpu_merge_segments": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(MergeParamsC),
@@ -83,6 +88,8 @@ ABI = {
                                              C.c_uint32, C.c_void_p, C.c_int, C.c_void_p,
                                              C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
     "mtgpu_pipe_create": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.POINTER(C.c_void_p)]),
+    "mtgpu_pipe_create_layout": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_int,
+                                           C.POINTER(C.c_void_p)]),
     "mtgpu_pipe_destroy": (None, [C.c_void_p]),
     "mtgpu_pipe_acquire": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "mtgpu_batch_add_frame": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_double, C.c_uint64]),

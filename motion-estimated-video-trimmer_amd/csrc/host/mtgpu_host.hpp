@@ -59,6 +59,11 @@ struct Config {   // same variables, defaults and parse types as config.hpp:56-1
   static double chunk_duration_sec() { return env_d("CHUNK_DURATION_SEC", 30.0); }
   static double target_fps() { return env_d("TARGET_FPS", 0.0); }
   static double min_savings_pct() { return env_d("MIN_SAVINGS_PCT", 5.0); }
+  // not in the reference: staging layout of the host dispatcher (include/mtgpu.h), "aos40" or "compact8"
+  static int staging_layout() {
+    const char *v = std::getenv("MTGPU_STAGING");
+    return (v && std::string(v) == "aos40") ? MT_LAYOUT_AOS40 : MT_LAYOUT_COMPACT8;
+  }
 };
 
 // ---------------------------------------------------------------- work / result plumbing
@@ -214,7 +219,8 @@ class GpuBackend {
                                       Config::block_shift(), Config::vectors_needed(), Config::clusters_needed(),
                                       Config::vertical_mask());
     if (rc == MT_OK) rc = mtgpu_create(&p, device, &ctx_);
-    if (rc == MT_OK) rc = mtgpu_pipe_create(ctx_, batch_records, batch_frames, n_buffers, &pipe_);
+    if (rc == MT_OK)
+      rc = mtgpu_pipe_create_layout(ctx_, batch_records, batch_frames, n_buffers, Config::staging_layout(), &pipe_);
     if (rc != MT_OK) { err = mtgpu_last_error(); reset(); return false; }
     width_ = width; height_ = height; device_ = device;
     return true;
@@ -275,10 +281,21 @@ class GpuMotionScanner {   // public shape of MotionScanner (motion_scanner.hpp:
   }
   GpuMotionScanner(const GpuMotionScanner &) = delete;
   GpuMotionScanner &operator=(const GpuMotionScanner &) = delete;
+  // Empty while every call so far succeeded.  scan_range keeps the reference's signature (it
+  // returns the timestamps), so a failed range is reported here: callers MUST check failed()
+  // after each scan_range — a range that failed returns only part of its timestamps.
   const std::string &error() const { return err_; }
+  bool failed() const { return !err_.empty(); }
   mtgpu_ctx *context() { return be_->ctx(); }
 
-  bool initialize(uint64_t batch_records = 1u << 17, uint32_t batch_frames = 256, int n_buffers = 3) {
+  // batch_records == 0: sized from the source — room for a few frames of one 40-byte record
+  // per 4x4 block (the finest partition H.264/HEVC export); a single frame beyond a whole
+  // batch still works (the pipe grows an empty batch, include/mtgpu.h).
+  bool initialize(uint64_t batch_records = 0, uint32_t batch_frames = 256, int n_buffers = 3) {
+    if (batch_records == 0) {
+      const uint64_t fine = (uint64_t)((src_.width() + 3) / 4) * (uint64_t)((src_.height() + 3) / 4);
+      batch_records = std::max<uint64_t>(1u << 17, 2 * fine);
+    }
     if (!be_->ensure(src_.width(), src_.height(), device_, batch_records, batch_frames, n_buffers, err_)) return false;
     pipe_ = be_->pipe();
     return true;
@@ -317,11 +334,20 @@ class GpuMotionScanner {   // public shape of MotionScanner (motion_scanner.hpp:
       auto a0 = clk::now();
       const bool fed = feed(f, pts, ts);                                 // copy-out + async scan (:376)
       analyze_us += us(a0, clk::now());
-      if (!fed) return ts;
+      if (!fed) break;                                                   // err_ is set: failed()
     }
     auto a0 = clk::now();
-    if (cur_ && mtgpu_batch_frames(cur_) > 0) submit();
-    while (inflight_ > 0) if (!collect_one(ts)) break;
+    if (!failed() && cur_ && mtgpu_batch_frames(cur_) > 0) submit();
+    if (failed()) {
+      // leave the pipe idle: finish what is in flight (results discarded), drop the partial batch
+      std::vector<double> sink;
+      const std::string first = err_;
+      while (inflight_ > 0 && collect_one(sink)) {}
+      if (cur_) { mtgpu_pipe_release(pipe_, cur_); cur_ = nullptr; }
+      err_ = first;
+    } else {
+      while (inflight_ > 0) if (!collect_one(ts)) break;
+    }
     analyze_us += us(a0, clk::now());
     return ts;
   }
@@ -332,6 +358,7 @@ struct PipelineResult {
   std::vector<mt_segment> segments;   // what FFmpegJob::segments would carry (pipeline.cpp:366, 396)
   mt_merge_result merge{};
   size_t motion_frames = 0;           // pooled timestamps before sort/unique (pipeline.cpp:294-295)
+  std::vector<double> timestamps;     // those timestamps, in pooling order (ResultCollector::extract, :268)
   int chunks = 0, threads = 0;
   long seek_us = 0, decode_us = 0, analyze_us = 0;   // summed over workers, as pipeline.cpp:229-233
   long init_us = 0, scan_wall_us = 0;                // worker init (summed) / wall time of the scan phase
@@ -383,6 +410,11 @@ int run_scan_pipeline(MakeSource make_source, int num_threads, PipelineResult &o
       ScanTask task;
       while (tasks.pop(task)) {                                          // :216-223
         auto r = scanners[i]->scan_range(task.start, task.end, s, d, a);
+        if (scanners[i]->failed()) {                                     // a failed range must fail the video
+          std::lock_guard<std::mutex> l(err_mu);
+          if (out.error.empty()) out.error = scanners[i]->error();
+          break;
+        }
         if (!r.empty()) results.add(std::move(r));
       }
       seek_us += s; decode_us += d; analyze_us += a;
@@ -396,7 +428,8 @@ int run_scan_pipeline(MakeSource make_source, int num_threads, PipelineResult &o
   out.scan_wall_us = (long)std::chrono::duration_cast<std::chrono::microseconds>(
                          std::chrono::high_resolution_clock::now() - wall0).count();
   if (!out.error.empty()) return 1;
-  std::vector<double> timestamps = results.extract();
+  out.timestamps = results.extract();
+  const std::vector<double> &timestamps = out.timestamps;
   out.motion_frames = timestamps.size();
   for (auto &s : scanners) if (s && s->context()) { merge_ctx = s->context(); break; }
   if (!merge_ctx) { out.error = "no scanner context"; return 1; }

@@ -1,6 +1,6 @@
 // mtgpu_scan_file — the scan + merge half of `motion_trim` on the GPU, reading extracted motion
 // vectors from .mtmv containers instead of decoding with FFmpeg:
-//   mtgpu_scan_file stream.mtmv [more.mtmv ...] [--threads T] [--streams S] [--outdir DIR]
+//   mtgpu_scan_file stream.mtmv [more.mtmv ...] [--threads T] [--streams S] [--outdir DIR] [--timestamps]
 // One file: like `motion_trim in out` (single ProcessingPipeline).  Several files: like
 // `motion_trim in_dir out_dir` (BatchProcessor): S streams x T workers, jobs consumed by one
 // thread (here: printed).  Configuration comes from the same environment variables as the
@@ -16,6 +16,8 @@
 
 using namespace mtgpu_host;
 
+static bool g_print_ts = false;   // --timestamps: also print the pooled motion timestamps, sorted (%.17g)
+
 static void print_job(const std::string &input, const PipelineResult &r, const std::vector<mt_segment> &segs) {
   std::printf("{\"input\": \"%s\", \"chunks\": %d, \"threads\": %d, \"motion_frames\": %zu, \"n_timestamps\": %llu, "
               "\"do_cut\": %d, \"time_removed\": %.17g, \"saved_pct\": %.17g, \"seek_us\": %ld, "
@@ -25,7 +27,15 @@ static void print_job(const std::string &input, const PipelineResult &r, const s
               r.scan_wall_us);
   for (size_t i = 0; i < segs.size(); ++i)
     std::printf("%s[%.17g, %.17g]", i ? ", " : "", segs[i].start, segs[i].end);
-  std::printf("]}\n");
+  std::printf("]");
+  if (g_print_ts) {
+    std::vector<double> ts = r.timestamps;
+    std::sort(ts.begin(), ts.end());
+    std::printf(", \"timestamps\": [");
+    for (size_t i = 0; i < ts.size(); ++i) std::printf("%s%.17g", i ? ", " : "", ts[i]);
+    std::printf("]");
+  }
+  std::printf("}\n");
   std::fflush(stdout);
 }
 
@@ -37,6 +47,7 @@ int main(int argc, char **argv) {
     if (!std::strcmp(argv[i], "--threads") && i + 1 < argc) threads = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--streams") && i + 1 < argc) streams = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--outdir") && i + 1 < argc) outdir = argv[++i];
+    else if (!std::strcmp(argv[i], "--timestamps")) g_print_ts = true;
     else files.push_back(argv[i]);
   }
   if (files.empty()) {

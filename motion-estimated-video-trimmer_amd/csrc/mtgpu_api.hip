@@ -77,6 +77,7 @@ struct mtgpu_ctx {
   int slices_request = 0;  // 0 = auto, else 1/2/4/8 (mtgpu_set_slices, MTGPU_FORCE_SLICES)
   int wide_chunk_rows = 0, wide_lds_bytes = 0;   // single-workgroup-per-CU layout (see make_plan)
   int item_chunk = 0;    // MTGPU_ITEM_CHUNK (tests): work items per kernel launch, 0 = 2^30
+  int lds_max = 0;       // device limit of LDS per workgroup
   std::mutex mu;         // guards the staging buffers below
   DevBuf d_mv, d_off, d_sd, d_flags, d_misc;
 };
@@ -151,22 +152,40 @@ int make_plan(mtgpu_ctx *c, int lds_max, int cu_count) {
   k.active_min = mode == 1 ? ((1u << vn) - 1u) : vn;         // thermometer full / binary count
 
   int band_rows = R, chunk_rows = R;
-  if (lds_need(R, R, k.gw, k.W, fb, nullptr) > (size_t)lds_max) {
+  // MTGPU_MAX_TILE_KB (experiments): largest single tile; beyond it the grid is cut into row bands
+  long single_max = lds_max;
+  {
+    const int tkb = env_int("MTGPU_MAX_TILE_KB", 0);
+    if (tkb > 0 && (long)tkb * 1024 < single_max) single_max = (long)tkb * 1024;
+  }
+  if (lds_need(R, R, k.gw, k.W, fb, nullptr) > (size_t)single_max) {
     // 1st choice: whole grid in one tile, phase 2 in row chunks through a smaller mask buffer
     const size_t cnt_only = lds_need(R, -2, k.gw, k.W, fb, nullptr);   // counters + total
-    const long room = (long)lds_max - (long)cnt_only;
+    const long room = single_max - (long)cnt_only;
     long ch = room / (long)mask_row - 2;
     if (ch > R) ch = R;
     if (ch >= 8 || ch >= R) {
       chunk_rows = (int)ch;
     } else {
-      // 2nd choice: row bands (each band re-reads the frame's records through L2 / Infinity Cache)
+      // 2nd choice: row bands walked by ONE workgroup per frame (scan_kernels.hip, SPILL): the
+      // records are still read once; later bands replay the queued votes.  Bands are therefore
+      // cheap, and a tile of at most half the LDS lets two workgroups share a CU (one streams
+      // while the other zeroes / runs its cluster test).  MTGPU_BAND_LDS_KB overrides the tile limit.
+      long tile_max = (long)lds_max / 2;
+      const int fkb = env_int("MTGPU_BAND_LDS_KB", 0);
+      if (fkb > 0) tile_max = (long)fkb * 1024 < (long)lds_max ? (long)fkb * 1024 : (long)lds_max;
       const size_t per_row = ((size_t)k.gw * (size_t)fb + 7u) / 8u + mask_row;
-      long r = ((long)lds_max - 64) / (long)per_row - 2;
-      while (r >= 1 && lds_need((int)r, (int)r, k.gw, k.W, fb, nullptr) > (size_t)lds_max) --r;
+      long r = 0;
+      for (int pass = 0; pass < 2 && r < 1; ++pass) {             // half LDS first, all of it if a row is that wide
+        const long lim = pass == 0 ? tile_max : (long)lds_max;
+        r = (lim - 64) / (long)per_row - 2;
+        while (r >= 1 && lds_need((int)r, (int)r, k.gw, k.W, fb, nullptr) > (size_t)lim) --r;
+      }
       if (r < 1)
         return fail(MT_ERR_CAPACITY, "grid width %d: three counter rows do not fit %d bytes of LDS", k.gw, lds_max);
-      band_rows = chunk_rows = (int)r;
+      if (r > R) r = R;
+      const long nb = ((long)R + r - 1) / r;                      // balance the bands
+      band_rows = chunk_rows = (int)(((long)R + nb - 1) / nb);
     }
   }
   // Two workgroups per CU hide each other's zero / cluster-test phases (measured +4 % on the
@@ -241,15 +260,18 @@ int choose_slices(const mtgpu_ctx *c, uint64_t n_records, uint32_t n_frames) {
 // Launches the scan on `st`; scratch (band centre counts, slice tiles + tickets) is allocated
 // and freed stream-ordered, so concurrent callers share nothing.
 int launch_scan_on(mtgpu_ctx *c, const void *d_mv, uint64_t n_records, const uint64_t *d_off,
-                   const uint8_t *d_sd, uint32_t n_frames, uint8_t *d_flags, hipStream_t st) {
+                   const uint8_t *d_sd, uint32_t n_frames, uint8_t *d_flags, hipStream_t st, int rec_bytes = MT_MV_BYTES) {
   mtgpu::ScanLaunch L;
+  L.rec_bytes = rec_bytes;
+  L.lds_max = c->lds_max;
+  L.device = c->device;
   L.mv = static_cast<const unsigned char *>(d_mv);
   L.n_records = n_records;
   L.frame_off = reinterpret_cast<const unsigned long long *>(d_off);
   L.has_sd = d_sd;
   L.n_frames = n_frames;
   L.flags = d_flags;
-  L.frame_centres = nullptr;
+  L.spill_q = nullptr;
   L.slice_ws = nullptr;
   L.tickets = nullptr;
   L.k = c->k;
@@ -267,13 +289,13 @@ int launch_scan_on(mtgpu_ctx *c, const void *d_mv, uint64_t n_records, const uin
   L.stream = st;
   void *scratch = nullptr;
   size_t bytes = 0;
-  if (L.k.bands > 1) bytes = sizeof(unsigned int) * (size_t)n_frames;
+  if (L.k.bands > 1) bytes = sizeof(unsigned int) * ((size_t)n_records + 4);   // spill queue: a slot per record
   if (L.k.slices > 1)
     bytes = sizeof(unsigned int) * ((size_t)n_frames * (size_t)L.k.slices * (size_t)L.k.cnt_words + (size_t)n_frames + 4);
   if (bytes) {
     hipError_t e = hipMallocAsync(&scratch, bytes, st);
     if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(scan scratch)");
-    if (L.k.bands > 1) L.frame_centres = static_cast<unsigned int *>(scratch);
+    if (L.k.bands > 1) L.spill_q = static_cast<unsigned int *>(scratch);
     if (L.k.slices > 1) {
       L.slice_ws = static_cast<unsigned int *>(scratch);
       L.tickets = L.slice_ws + (((size_t)n_frames * (size_t)L.k.slices * (size_t)L.k.cnt_words + 3) & ~(size_t)3);
@@ -292,16 +314,25 @@ int launch_scan_on(mtgpu_ctx *c, const void *d_mv, uint64_t n_records, const uin
 }  // namespace
 
 namespace mtgpu {
+// Data movement only (no result is computed on the host): bytes 6..13 of every 40-byte
+// AVMotionVector -> one packed 8-byte record.
+void pack_records(const unsigned char *mv, uint64_t n, unsigned char *out) {
+  for (uint64_t i = 0; i < n; ++i) {
+    uint64_t v;
+    std::memcpy(&v, mv + i * MT_MV_BYTES + 6, 8);
+    std::memcpy(out + i * MT_COMPACT_BYTES, &v, 8);
+  }
+}
 int ctx_device(const mtgpu_ctx *c) { return c->device; }
 int ctx_launch_scan(mtgpu_ctx *c, const void *d_mv, uint64_t n_records, const uint64_t *d_off,
-                    const uint8_t *d_sd, uint32_t n_frames, uint8_t *d_flags, hipStream_t st) {
-  return launch_scan_on(c, d_mv, n_records, d_off, d_sd, n_frames, d_flags, st);
+                    const uint8_t *d_sd, uint32_t n_frames, uint8_t *d_flags, hipStream_t st, int rec_bytes) {
+  return launch_scan_on(c, d_mv, n_records, d_off, d_sd, n_frames, d_flags, st, rec_bytes);
 }
 }  // namespace mtgpu
 
 extern "C" {
 
-const char *mtgpu_version(void) { return "mtgpu 0.1 (gfx950 MV scan + segment merge)"; }
+const char *mtgpu_version(void) { return "mtgpu 0.2 (gfx950 MV scan + segment merge)"; }
 
 const char *mtgpu_last_error(void) { return g_err; }
 
@@ -352,6 +383,7 @@ int mtgpu_create(const mt_scan_params *params, int device, mtgpu_ctx **out) {
   if (!c) return fail(MT_ERR_NOMEM, "out of host memory");
   c->params = *params;
   c->device = device;
+  c->lds_max = lds_max;
   c->stream = nullptr;
   rc = make_plan(c, lds_max, cus);
   if (rc != MT_OK) { delete c; return rc; }
@@ -392,6 +424,26 @@ int mtgpu_scan_frames_device(mtgpu_ctx *c, const void *d_mv, uint64_t n_records,
   HIP_TRY(hipSetDevice(c->device));
   return launch_scan_on(c, d_mv, n_records, d_frame_off, d_has_sd, n_frames, d_flags,
                         static_cast<hipStream_t>(stream));
+}
+
+int mtgpu_scan_frames_device_compact(mtgpu_ctx *c, const void *d_rec8, uint64_t n_records,
+                                     const uint64_t *d_frame_off, const uint8_t *d_has_sd,
+                                     uint32_t n_frames, uint8_t *d_flags, void *stream) {
+  if (!c) return fail(MT_ERR_INVALID, "ctx is NULL");
+  if (n_frames == 0) return MT_OK;
+  if (!d_frame_off || !d_flags) return fail(MT_ERR_INVALID, "frame_off/flags is NULL");
+  if (n_records > 0 && !d_rec8) return fail(MT_ERR_INVALID, "records is NULL with n_records > 0");
+  if (((uintptr_t)d_rec8 & 7u) != 0) return fail(MT_ERR_INVALID, "compact records must be 8-byte aligned");
+  HIP_TRY(hipSetDevice(c->device));
+  return launch_scan_on(c, d_rec8, n_records, d_frame_off, d_has_sd, n_frames, d_flags,
+                        static_cast<hipStream_t>(stream), MT_COMPACT_BYTES);
+}
+
+int mtgpu_pack_records(const void *mv_bytes, uint64_t n_records, void *out8) {
+  if (n_records == 0) return MT_OK;
+  if (!mv_bytes || !out8) return fail(MT_ERR_INVALID, "NULL argument");
+  mtgpu::pack_records(static_cast<const unsigned char *>(mv_bytes), n_records, static_cast<unsigned char *>(out8));
+  return MT_OK;
 }
 
 int mtgpu_debug_read_ceiling(mtgpu_ctx *c, const void *d_buf, uint64_t bytes, void *stream) {

@@ -3,8 +3,20 @@
 // Replaces the synchronous check_frame call in the decode loop
 // (reference src/motion_scanner.cpp:375-383) and the copy-out that the MV side
 // data's lifetime (:347) forces on any batched backend.
+//
+// Staging layout: MT_LAYOUT_COMPACT8 (default) copies only bytes 6..13 of every 40-byte
+// AVMotionVector (src_x, src_y, dst_x, dst_y — all check_frame reads) into pinned memory, so
+// 8 instead of 40 bytes per record cross PCIe and the scan reads the 8-byte records
+// (scan_kernels.hip, REC 8); MT_LAYOUT_AOS40 stages the records unchanged.
+//
+// Batch states: 0 free -> (acquire) 1 filling -> (submit) 2 in flight -> (collect) 3 collected
+// -> (release) 0.  A failed submit drains the batch's stream and leaves it in state 1 with its
+// contents intact (retry or release); a failed collect still hands the batch out (state 3) so
+// that it can be released: an error never strands a staging buffer.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <mutex>
@@ -28,6 +40,7 @@ struct mtgpu_batch {
   uint8_t *d_flags = nullptr;
   uint64_t cap_records = 0, n_records = 0;
   uint32_t cap_frames = 0, n_frames = 0;
+  int rec_bytes = MT_COMPACT_BYTES;   // bytes per staged record: 8 (compact) or 40 (AoS)
   hipStream_t stream = nullptr;
   hipEvent_t done = nullptr;
   int state = 0;   // 0 free, 1 filling, 2 in flight, 3 collected
@@ -36,6 +49,9 @@ struct mtgpu_batch {
 
 struct mtgpu_pipe {
   mtgpu_ctx *ctx = nullptr;
+  int rec_bytes = MT_COMPACT_BYTES;
+  long inject_submit_fail = 0;   // MTGPU_INJECT_SUBMIT_FAIL=k (tests): the k-th submit fails after its copies were queued
+  long submits = 0;
   std::vector<mtgpu_batch *> bufs;
   std::deque<mtgpu_batch *> inflight;
   std::mutex mu;
@@ -70,22 +86,37 @@ void free_batch(mtgpu_batch *b) {
     if (_e != hipSuccess) { rc = hip_fail(_e, #expr); goto bad; }    \
   } while (0)
 
-int alloc_batch(mtgpu_batch **out, uint64_t max_records, uint32_t max_frames) {
+// (Re)allocate the record staging of a batch for `records` records; the batch must be idle.
+int alloc_records(mtgpu_batch *b, uint64_t records) {
+  int rc = MT_OK;
+  if (b->h_mv) (void)hipHostFree(b->h_mv);
+  if (b->d_mv) (void)hipFree(b->d_mv);
+  b->h_mv = nullptr; b->d_mv = nullptr; b->cap_records = 0;
+  const size_t mvb = (size_t)records * (size_t)b->rec_bytes + 64;
+  PIPE_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_mv), mvb, hipHostMallocDefault));
+  PIPE_TRY(hipMalloc(reinterpret_cast<void **>(&b->d_mv), mvb));
+  b->cap_records = records;
+  return MT_OK;
+bad:
+  if (b->h_mv) (void)hipHostFree(b->h_mv);
+  b->h_mv = nullptr;
+  return rc;
+}
+
+int alloc_batch(mtgpu_batch **out, uint64_t max_records, uint32_t max_frames, int rec_bytes) {
   int rc = MT_OK;
   mtgpu_batch *b = new (std::nothrow) mtgpu_batch();
   if (!b) return fail(MT_ERR_NOMEM, "out of host memory");
-  b->cap_records = max_records;
   b->cap_frames = max_frames;
+  b->rec_bytes = rec_bytes;
+  if ((rc = alloc_records(b, max_records)) != MT_OK) { free_batch(b); return rc; }
   {
-    const size_t mvb = (size_t)max_records * MT_MV_BYTES + 64;
     const size_t nf = (size_t)max_frames;
-    PIPE_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_mv), mvb, hipHostMallocDefault));
     PIPE_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_off), sizeof(uint64_t) * (nf + 1), hipHostMallocDefault));
     PIPE_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_sd), nf + 1, hipHostMallocDefault));
     PIPE_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_pts), sizeof(double) * (nf + 1), hipHostMallocDefault));
     PIPE_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_tag), sizeof(uint64_t) * (nf + 1), hipHostMallocDefault));
     PIPE_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_flags), nf + 1, hipHostMallocDefault));
-    PIPE_TRY(hipMalloc(reinterpret_cast<void **>(&b->d_mv), mvb));
     PIPE_TRY(hipMalloc(reinterpret_cast<void **>(&b->d_off), sizeof(uint64_t) * (nf + 1)));
     PIPE_TRY(hipMalloc(reinterpret_cast<void **>(&b->d_sd), nf + 1));
     PIPE_TRY(hipMalloc(reinterpret_cast<void **>(&b->d_flags), nf + 1));
@@ -106,8 +137,16 @@ extern "C" {
 
 int mtgpu_pipe_create(mtgpu_ctx *ctx, uint64_t max_records_per_batch, uint32_t max_frames_per_batch,
                       int n_buffers, mtgpu_pipe **out) {
+  return mtgpu_pipe_create_layout(ctx, max_records_per_batch, max_frames_per_batch, n_buffers,
+                                  MT_LAYOUT_COMPACT8, out);
+}
+
+int mtgpu_pipe_create_layout(mtgpu_ctx *ctx, uint64_t max_records_per_batch, uint32_t max_frames_per_batch,
+                             int n_buffers, int layout, mtgpu_pipe **out) {
   if (!ctx || !out) return fail(MT_ERR_INVALID, "NULL argument");
   *out = nullptr;
+  if (layout != MT_LAYOUT_COMPACT8 && layout != MT_LAYOUT_AOS40)
+    return fail(MT_ERR_INVALID, "layout must be MT_LAYOUT_COMPACT8 or MT_LAYOUT_AOS40");
   if (max_records_per_batch == 0 || max_frames_per_batch == 0 || n_buffers < 1 || n_buffers > 64)
     return fail(MT_ERR_INVALID, "pipe needs max_records > 0, max_frames > 0, 1 <= n_buffers <= 64");
   hipError_t e = hipSetDevice(mtgpu::ctx_device(ctx));
@@ -115,9 +154,11 @@ int mtgpu_pipe_create(mtgpu_ctx *ctx, uint64_t max_records_per_batch, uint32_t m
   mtgpu_pipe *p = new (std::nothrow) mtgpu_pipe();
   if (!p) return fail(MT_ERR_NOMEM, "out of host memory");
   p->ctx = ctx;
+  p->rec_bytes = layout == MT_LAYOUT_AOS40 ? MT_MV_BYTES : MT_COMPACT_BYTES;
+  if (const char *v = std::getenv("MTGPU_INJECT_SUBMIT_FAIL")) p->inject_submit_fail = std::atol(v);
   for (int i = 0; i < n_buffers; ++i) {
     mtgpu_batch *b = nullptr;
-    int rc = alloc_batch(&b, max_records_per_batch, max_frames_per_batch);
+    int rc = alloc_batch(&b, max_records_per_batch, max_frames_per_batch, p->rec_bytes);
     if (rc != MT_OK) { mtgpu_pipe_destroy(p); return rc; }
     b->owner = p;
     p->bufs.push_back(b);
@@ -155,12 +196,20 @@ int mtgpu_batch_add_frame(mtgpu_batch *b, const void *mv_bytes, uint64_t n_bytes
   if (b->state != 1) return fail(MT_ERR_INVALID, "batch is not being filled (acquire it first)");
   const uint64_t n = (mv_bytes && has_side_data) ? n_bytes / MT_MV_BYTES : 0;   // :226 integer division
   if (b->n_frames >= b->cap_frames || b->n_records + n > b->cap_records) {
-    if (b->n_frames == 0 && n > b->cap_records)
-      return fail(MT_ERR_INVALID, "a frame of %llu records exceeds the pipe's batch capacity %llu",
-                  (unsigned long long)n, (unsigned long long)b->cap_records);
-    return fail(MT_ERR_CAPACITY, "batch full");
+    if (b->n_frames != 0 || n <= b->cap_records) return fail(MT_ERR_CAPACITY, "batch full");
+    // One frame larger than a whole batch (check_frame accepts any count, :226): grow this
+    // batch's staging.  The batch is empty and idle (its previous work was collected), so its
+    // buffers can be replaced.
+    hipError_t e = hipSetDevice(mtgpu::ctx_device(b->owner->ctx));
+    if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+    int rc = alloc_records(b, n + n / 4);
+    if (rc != MT_OK) return rc;
   }
-  if (n) std::memcpy(b->h_mv + (size_t)b->n_records * MT_MV_BYTES, mv_bytes, (size_t)n * MT_MV_BYTES);
+  if (n) {
+    unsigned char *dst = b->h_mv + (size_t)b->n_records * (size_t)b->rec_bytes;
+    if (b->rec_bytes == MT_MV_BYTES) std::memcpy(dst, mv_bytes, (size_t)n * MT_MV_BYTES);
+    else mtgpu::pack_records(static_cast<const unsigned char *>(mv_bytes), n, dst);   // bytes 6..13 only
+  }
   const uint32_t f = b->n_frames;
   b->n_records += n;
   b->h_off[f + 1] = b->n_records;
@@ -179,26 +228,40 @@ int mtgpu_pipe_submit(mtgpu_pipe *p, mtgpu_batch *b) {
   hipError_t e = hipSetDevice(mtgpu::ctx_device(p->ctx));
   if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
   hipStream_t st = b->stream;
+  int rc = MT_OK;
+  long nth;
+  { std::lock_guard<std::mutex> lock(p->mu); nth = ++p->submits; }
   if (b->n_frames) {
-    if (b->n_records) {
-      e = hipMemcpyAsync(b->d_mv, b->h_mv, (size_t)b->n_records * MT_MV_BYTES, hipMemcpyHostToDevice, st);
-      if (e != hipSuccess) return hip_fail(e, "H2D records");
+    if (b->n_records)
+      PIPE_TRY(hipMemcpyAsync(b->d_mv, b->h_mv, (size_t)b->n_records * (size_t)b->rec_bytes, hipMemcpyHostToDevice, st));
+    PIPE_TRY(hipMemcpyAsync(b->d_off, b->h_off, sizeof(uint64_t) * ((size_t)b->n_frames + 1), hipMemcpyHostToDevice, st));
+    PIPE_TRY(hipMemcpyAsync(b->d_sd, b->h_sd, b->n_frames, hipMemcpyHostToDevice, st));
+    if (p->inject_submit_fail > 0 && nth == p->inject_submit_fail) {
+      rc = fail(MT_ERR_DEVICE, "injected submit failure (MTGPU_INJECT_SUBMIT_FAIL)");
+      goto bad;
     }
-    e = hipMemcpyAsync(b->d_off, b->h_off, sizeof(uint64_t) * ((size_t)b->n_frames + 1), hipMemcpyHostToDevice, st);
-    if (e != hipSuccess) return hip_fail(e, "H2D offsets");
-    e = hipMemcpyAsync(b->d_sd, b->h_sd, b->n_frames, hipMemcpyHostToDevice, st);
-    if (e != hipSuccess) return hip_fail(e, "H2D has_sd");
-    int rc = mtgpu::ctx_launch_scan(p->ctx, b->d_mv, b->n_records, b->d_off, b->d_sd, b->n_frames, b->d_flags, st);
-    if (rc != MT_OK) return rc;
-    e = hipMemcpyAsync(b->h_flags, b->d_flags, b->n_frames, hipMemcpyDeviceToHost, st);
-    if (e != hipSuccess) return hip_fail(e, "D2H flags");
+    rc = mtgpu::ctx_launch_scan(p->ctx, b->d_mv, b->n_records, b->d_off, b->d_sd, b->n_frames, b->d_flags, st,
+                                b->rec_bytes);
+    if (rc != MT_OK) goto bad;
+    PIPE_TRY(hipMemcpyAsync(b->h_flags, b->d_flags, b->n_frames, hipMemcpyDeviceToHost, st));
   }
-  e = hipEventRecord(b->done, st);
-  if (e != hipSuccess) return hip_fail(e, "hipEventRecord");
-  std::lock_guard<std::mutex> lock(p->mu);
-  b->state = 2;
-  p->inflight.push_back(b);
+  PIPE_TRY(hipEventRecord(b->done, st));
+  {
+    std::lock_guard<std::mutex> lock(p->mu);
+    b->state = 2;
+    p->inflight.push_back(b);
+  }
   return MT_OK;
+bad:
+  // Copies / kernels of this batch may already be queued: let them finish before the caller can
+  // touch the pinned staging again.  The batch stays in state 1 (contents intact).
+  {
+    char keep[512];
+    std::snprintf(keep, sizeof keep, "%s", mtgpu_last_error());
+    (void)hipStreamSynchronize(st);
+    (void)fail(rc, "%s", keep);
+  }
+  return rc;
 }
 
 int mtgpu_pipe_collect(mtgpu_pipe *p, mtgpu_batch **out, const uint8_t **flags, const double **pts,
@@ -212,9 +275,9 @@ int mtgpu_pipe_collect(mtgpu_pipe *p, mtgpu_batch **out, const uint8_t **flags, 
     p->inflight.pop_front();
     b->state = 3;
   }
+  *out = b;                       // handed out even on failure, so that it can be released
   hipError_t e = hipEventSynchronize(b->done);
   if (e != hipSuccess) return hip_fail(e, "hipEventSynchronize");
-  *out = b;
   if (flags) *flags = b->h_flags;
   if (pts) *pts = b->h_pts;
   if (tags) *tags = b->h_tag;

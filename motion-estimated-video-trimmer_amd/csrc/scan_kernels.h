@@ -16,7 +16,7 @@ struct ScanK {
   unsigned int vec_need;   // vectors_needed                  (:272)
   unsigned int clust_need; // max(1, clusters_needed)         (:288)
   int W;                   // 64-bit words per activity-mask row = ceil(gw / 64)
-  int bands;               // row bands per frame
+  int bands;               // row bands per frame (> 1: one workgroup walks them, spilling votes to a queue)
   int band_rows;           // analysed rows per band
   int fb;                  // bits per LDS vote counter: 32, or 1/2/4/8 packed
   int mode;                // 0 ADD32 (fb 32), 1 UNARY thermometer (vec_need <= fb), 2 CAS (fb 8)
@@ -34,7 +34,7 @@ struct ScanLaunch {
   const unsigned char *has_sd;
   unsigned int n_frames;
   unsigned char *flags;
-  unsigned int *frame_centres;  // n_frames words, only when k.bands > 1
+  unsigned int *spill_q;        // n_records words (one slot per record), only when k.bands > 1
   unsigned int *slice_ws;       // n_frames * slices * cnt_words words, only when k.slices > 1
   unsigned int *tickets;        // n_frames words (zeroed by launch_scan), only when k.slices > 1
   ScanK k;
@@ -42,6 +42,9 @@ struct ScanLaunch {
   int variant;             // experiment knob (MTGPU_VARIANT), 0 = shipped kernel
   unsigned long long item_chunk;  // work items per launch (0 = 2^30; MTGPU_ITEM_CHUNK shrinks it for tests)
   int lds_bytes;
+  int lds_max;             // device limit of dynamic LDS per workgroup (set once per kernel instantiation)
+  int device;
+  int rec_bytes;           // 40 = AVMotionVector records, 8 = compact {src_x,src_y,dst_x,dst_y}
   hipStream_t stream;
 };
 

@@ -2,10 +2,11 @@
 // (reference: src/motion_scanner.cpp:217-295).  Integer threshold / scatter /
 // stencil work: HBM-read bound, no MFMA.
 //
-// Work item = (frame, row band).  One workgroup per item:
-//   phase 0  zero the band's vote counters in LDS                  (:229 memset)
-//   phase 1  stream the frame's packed 40-byte records, one record per lane and
-//            load (bytes 4..15 of each record = w,h,src_x,src_y,dst_x,dst_y),
+// Work item = frame (or frame slice).  One workgroup per item:
+//   phase 0  zero the vote counters in LDS                         (:229 memset)
+//   phase 1  stream the frame's packed records, one record per lane and load
+//            (REC 40: bytes 4..15 of each AVMotionVector = w,h,src_x,src_y,dst_x,dst_y;
+//             REC 8: the compact src_x,src_y,dst_x,dst_y form the host dispatcher stages),
 //            threshold on |d|^2, map dst to a cell, vote in LDS     (:242-268)
 //   phase 2  per chunk of rows:
 //     2a     one wave per (row, 64-cell word): `count >= vectors_needed`
@@ -30,8 +31,22 @@
 //   every record is read from HBM once.
 // The early `return true` (:288-289) does not change the value:
 // result = (#centre cells >= max(1, clusters_needed)).
+//
+// Grids whose counters do not fit one LDS tile even packed are cut into ROW BANDS that the
+// SAME workgroup handles one after the other (template SPILL): the records are streamed from
+// HBM exactly once, during band 0; every surviving vote that a later band needs is appended to
+// a per-frame queue in global memory (4 bytes: gy << 16 | gx; wave-aggregated append, the tail
+// lives in LDS) and bands 1.. replay that queue instead of re-reading 40-byte records.  Typical
+// footage queues almost nothing (only votes above the threshold); the worst case (every record
+// votes, all into later bands) adds 4 B written + 4 B per later band read to each 40-B record.
+#if !defined(__HIP_DEVICE_COMPILE__) || defined(__gfx950__)
+#else
+#error "scan_kernels.hip is written for gfx950 only (sc1 write-through stores, aux bits, 160 KB LDS)"
+#endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <atomic>
 
 #include "scan_kernels.h"
 
@@ -58,6 +73,35 @@ __device__ __forceinline__ u32x3 load_fields(const unsigned char *rec) {
     if constexpr ((VAR & 4) != 0) return *reinterpret_cast<const u32x3_a4 *>(rec + 4);
     else return __builtin_nontemporal_load(reinterpret_cast<const u32x3_a4 *>(rec + 4));
   }
+}
+
+// Compact record (REC 8): src_x | src_y << 16, dst_x | dst_y << 16 — bytes 6..13 of an
+// AVMotionVector, packed by the host dispatcher (pipe.hip) or mtgpu_pack_records.
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef u32x2 u32x2_a8 __attribute__((aligned(8)));
+
+template <int VAR>
+__device__ __forceinline__ u32x2 load_compact(const unsigned char *rec) {
+  if constexpr ((VAR & 4) != 0) return *reinterpret_cast<const u32x2_a8 *>(rec);
+  else return __builtin_nontemporal_load(reinterpret_cast<const u32x2_a8 *>(rec));
+}
+
+template <int REC> struct RawOf { typedef u32x3 type; };
+template <> struct RawOf<8> { typedef u32x2 type; };
+
+template <int VAR, int REC>
+__device__ __forceinline__ typename RawOf<REC>::type load_rec(const unsigned char *rec) {
+  if constexpr (REC == 8) return load_compact<VAR>(rec);
+  else return load_fields<VAR>(rec);
+}
+
+struct MvFields { int src_x, src_y, dst_x, dst_y; };
+
+__device__ __forceinline__ MvFields decode(const u32x3 d) {
+  return {(int)d.x >> 16, (int)(short)(d.y & 0xffffu), (int)d.y >> 16, (int)(short)(d.z & 0xffffu)};
+}
+__device__ __forceinline__ MvFields decode(const u32x2 d) {
+  return {(int)(short)(d.x & 0xffffu), (int)d.x >> 16, (int)(short)(d.y & 0xffffu), (int)d.y >> 16};
 }
 
 enum { MODE_ADD32 = 0, MODE_UNARY = 1, MODE_CAS = 2 };
@@ -125,246 +169,275 @@ __device__ __forceinline__ unsigned int combine_words(unsigned int a, unsigned i
   }
 }
 
+// Where a spilling workgroup (SPILL) keeps the votes later bands need.
+struct SpillQ {
+  unsigned int *q;        // this frame's queue: one slot per record of the frame
+  unsigned int *tail;     // entries so far (LDS)
+  int q_lo;               // first grid row a later band tracks (band 0's last centre row)
+};
+
 // Threshold + cell mapping + vote for one record (src/motion_scanner.cpp:246-267).
-template <int FB, int MODE>
-__device__ __forceinline__ void vote(const u32x3 d, const ScanK &k, int t0, int t1,
-                                     unsigned int *cnt) {
-  const int src_x = (int)d.x >> 16;
-  const int src_y = (int)(short)(d.y & 0xffffu);
-  const int dst_x = (int)d.y >> 16;
-  const int dst_y = (int)(short)(d.z & 0xffffu);
-  const unsigned int dx = (unsigned int)(dst_x - src_x);   // |dx| <= 65535
-  const unsigned int dy = (unsigned int)(dst_y - src_y);
+// [t0,t1) = grid rows this tile tracks.
+template <int FB, int MODE, bool SPILL>
+__device__ __forceinline__ void vote(const MvFields m, const ScanK &k, int t0, int t1,
+                                     unsigned int *cnt, const SpillQ &sq) {
+  const unsigned int dx = (unsigned int)(m.dst_x - m.src_x);   // |dx| <= 65535
+  const unsigned int dy = (unsigned int)(m.dst_y - m.src_y);
   // dx*dx < 2^32 exactly; the sum needs 34 bits.
   const unsigned long long mag =
       (unsigned long long)(dx * dx) + (unsigned long long)(dy * dy);
-  const int gx = dst_x >> k.shift;
-  const int gy = dst_y >> k.shift;
-  const bool in = (mag >= k.thr) & (gx >= 0) & (gx < k.gw) & (gy >= k.y_lo) & (gy < k.y_hi) &
-                  (gy >= t0) & (gy < t1);
-  if (in) bump<FB, MODE>(cnt, (unsigned int)((gy - t0) * k.gw + gx), k.vec_need);
+  const int gx = m.dst_x >> k.shift;
+  const int gy = m.dst_y >> k.shift;
+  const bool in = (mag >= k.thr) & (gx >= 0) & (gx < k.gw) & (gy >= k.y_lo) & (gy < k.y_hi);
+  if (in & (gy >= t0) & (gy < t1)) bump<FB, MODE>(cnt, (unsigned int)((gy - t0) * k.gw + gx), k.vec_need);
+  if constexpr (SPILL) {
+    // wave-aggregated append: one returning LDS add per wave instruction, contiguous stores
+    const bool qv = in & (gy >= sq.q_lo);
+    const unsigned long long qm = __ballot(qv);
+    if (qm != 0ull) {
+      const int lane = (int)(threadIdx.x & 63u);
+      const int leader = __ffsll((long long)qm) - 1;
+      unsigned int base = 0u;
+      if (lane == leader) base = atomicAdd(sq.tail, (unsigned int)__popcll(qm));
+      base = (unsigned int)__shfl((int)base, leader);
+      if (qv) sq.q[base + (unsigned int)__popcll(qm & ((1ull << lane) - 1ull))] = ((unsigned int)gy << 16) | (unsigned int)gx;
+    }
+  }
 }
 
-template <int BLOCK, int UNROLL, int FB, int MODE, int VAR>
+template <int BLOCK, int UNROLL, int FB, int MODE, int VAR, int REC, bool SPILL>
 __global__ __launch_bounds__(BLOCK) void scan_frames_kernel(
     const unsigned char *__restrict__ mv, unsigned long long n_records,
     const unsigned long long *__restrict__ frame_off, const unsigned char *__restrict__ has_sd,
     unsigned int item0, unsigned int n_frames, ScanK k, unsigned char *__restrict__ flags,
-    unsigned int *__restrict__ frame_centres, unsigned int *slice_ws, unsigned int *tickets) {
+    unsigned int *spill_q, unsigned int *slice_ws, unsigned int *tickets) {
   extern __shared__ __attribute__((aligned(16))) unsigned int lds[];
+  typedef typename RawOf<REC>::type Raw;
   const int tid = threadIdx.x;
   const unsigned int item = item0 + blockIdx.x;
-  // item -> (frame, band) or (frame, slice): bands and slices are never both > 1
-  unsigned int f;
-  int band = 0, slice = 0;
-  if (k.bands > 1) {
-    // Bands of one frame re-read the same records: put them on ONE XCD so that the later reader
-    // hits that XCD's L2.  Workgroups b and b+8 share an XCD (round-robin dispatch; speed only,
-    // never correctness): within a group of 8 frames, frame = item % 8, band = (item / 8) % bands.
-    const unsigned int span = 8u * (unsigned int)k.bands;
-    const unsigned int grp = item / span, l = item - grp * span;
-    f = grp * 8u + (l & 7u);
-    band = (int)(l >> 3);
-    if (f >= n_frames) return;
-  } else {
-    f = item / (unsigned int)k.slices;
-    slice = (int)(item - f * (unsigned int)k.slices);
-  }
+  // item -> frame, or (frame, slice): bands and slices are never both > 1
+  const unsigned int f = SPILL ? item : item / (unsigned int)k.slices;
+  const int slice = SPILL ? 0 : (int)(item - f * (unsigned int)k.slices);
 
   unsigned long long r0 = frame_off[f], r1 = frame_off[f + 1];
   r1 = r1 < n_records ? r1 : n_records;
   r0 = r0 < r1 ? r0 : r1;
   const bool sd = has_sd ? (has_sd[f] != 0) : (r1 > r0);
   if (!sd) {                                   // :219-221 — no side data: false
-    if (k.bands == 1 && slice == 0 && tid == 0) flags[f] = 0;
-    return;                                    // (bands > 1: finalize kernel writes 0)
+    if (slice == 0 && tid == 0) flags[f] = 0;
+    return;
   }
-  if (k.slices > 1) {                          // this workgroup's share of the frame's records
+  const unsigned long long q0 = r0;            // the frame's spill queue: one slot per record
+  if (!SPILL && k.slices > 1) {                // this workgroup's share of the frame's records
     const unsigned long long n = r1 - r0, per = (n + (unsigned long long)k.slices - 1ull) / (unsigned long long)k.slices;
     const unsigned long long a = r0 + min(n, per * (unsigned long long)slice);
     const unsigned long long b = r0 + min(n, per * (unsigned long long)(slice + 1));
     r0 = a;
     r1 = b;
   }
-
-  // Band geometry: centres [c0,c1), tracked counter rows [t0,t1).
-  const int c0 = k.y_lo + band * k.band_rows;
-  const int c1 = min(k.y_hi, c0 + k.band_rows);
-  const int t0 = max(c0 - 1, 0);
-  const int t1 = min(c1 + 1, k.gh);
-  const int trows = t1 - t0;                   // may be <= 0 for an empty analysed range
   const int W = k.W;
-
   unsigned int *cnt = lds;                                         // packed [trows][gw] fields
   unsigned long long *mask =
       reinterpret_cast<unsigned long long *>(lds + k.cnt_words);   // [chunk_rows+2][W]
   unsigned int *total = reinterpret_cast<unsigned int *>(mask + (size_t)k.mask_rows * W);
   unsigned int *ticket = total + 1;
+  SpillQ sq;
+  sq.q = SPILL ? spill_q + q0 : nullptr;
+  sq.tail = total + 2;
+  sq.q_lo = min(k.y_hi, k.y_lo + k.band_rows) - 1;                 // band 0's last centre row
 
-  // ---- phase 0: zero counters and the centre total
-  {
-    u32x4 *c4 = reinterpret_cast<u32x4 *>(cnt);
-    const int n4 = k.cnt_words >> 2;
-    for (int i = tid; i < n4; i += BLOCK) c4[i] = (u32x4){0u, 0u, 0u, 0u};
-    if (tid == 0) *total = 0u;
-  }
-  __syncthreads();
-
-  // ---- phase 1: stream the records
-  if (trows > 0 && k.vec_need != 0u) {         // vec_need == 0: every cell is active anyway
-    const unsigned char *base = mv + r0 * 40ull;
-    const unsigned long long n = r1 - r0;
-    unsigned long long i = tid;
-    constexpr unsigned long long STEP = (unsigned long long)UNROLL * BLOCK;
-    constexpr unsigned long long LAST = (unsigned long long)(UNROLL - 1) * BLOCK;
-    if constexpr ((VAR & 8) != 0) {
-      // software-pipelined: the next batch of loads is issued before this batch is consumed
-      u32x3 cur[UNROLL], nxt[UNROLL];
-      bool have = i + LAST < n;
-      if (have) {
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) cur[u] = load_fields<VAR>(base + (i + (unsigned long long)u * BLOCK) * 40ull);
-      }
-      while (have) {
-        const unsigned long long j = i + STEP;
-        const bool more = j + LAST < n;
-        if (more) {
-#pragma unroll
-          for (int u = 0; u < UNROLL; ++u) nxt[u] = load_fields<VAR>(base + (j + (unsigned long long)u * BLOCK) * 40ull);
-        }
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) vote<FB, MODE>(cur[u], k, t0, t1, cnt);
-        if (more) {
-#pragma unroll
-          for (int u = 0; u < UNROLL; ++u) cur[u] = nxt[u];
-        }
-        i = j;
-        have = more;
-      }
-    } else {
-      // main body: UNROLL independent loads in flight per lane
-      for (; i + LAST < n; i += STEP) {
-        u32x3 d[UNROLL];
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) d[u] = load_fields<VAR>(base + (i + (unsigned long long)u * BLOCK) * 40ull);
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) vote<FB, MODE>(d[u], k, t0, t1, cnt);
-      }
-    }
-    for (; i < n; i += BLOCK) vote<FB, MODE>(load_fields<VAR>(base + i * 40ull), k, t0, t1, cnt);
-  }
-  __syncthreads();
-
-  // ---- slices: publish this partial grid; the LAST workgroup of the frame to arrive sums them
-  // (no workgroup ever waits for another: nothing to deadlock on).  Hand-off (Guideline 16, R1
-  // in its counter form): 16-byte WRITE-THROUGH (sc1) stores, so no release fence and no L2
-  // write-back -> every storing wave drains -> barrier -> one lane's agent-scope ticket add;
-  // the last arriver does ONE agent-scope acquire (drops this CU's stale L1 lines: the
-  // stream-ordered workspace is reused by later launches), then plain loads.
-  if (k.slices > 1) {
-    const size_t words = (size_t)k.cnt_words;
-    unsigned int *mine = slice_ws + ((size_t)f * (size_t)k.slices + (size_t)slice) * words;
-    {
-      const u32x4 *c4 = reinterpret_cast<const u32x4 *>(cnt);
-      const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(mine, 0, k.cnt_words * 4, 0x00020000);
-      for (int i = tid; i < (k.cnt_words >> 2); i += BLOCK)
-        __builtin_amdgcn_raw_buffer_store_b128(c4[i], rsrc, i * 16, 0, /*aux: sc1*/ 16);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0)
-      *ticket = __hip_atomic_fetch_add(&tickets[f], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    if (*ticket != (unsigned int)(k.slices - 1)) return;       // not the last: done
-    if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
-    for (int s2 = 0; s2 < k.slices; ++s2) {
-      if (s2 == slice) continue;
-      const u32x4 *g4 = reinterpret_cast<const u32x4 *>(slice_ws + ((size_t)f * (size_t)k.slices + (size_t)s2) * words);
-      u32x4 *c4 = reinterpret_cast<u32x4 *>(cnt);
-      for (int i = tid; i < (k.cnt_words >> 2); i += BLOCK) {
-        const u32x4 o = g4[i];
-        u32x4 m = c4[i];
-        m.x = combine_words<FB, MODE>(m.x, o.x, k.vec_need);
-        m.y = combine_words<FB, MODE>(m.y, o.y, k.vec_need);
-        m.z = combine_words<FB, MODE>(m.z, o.z, k.vec_need);
-        m.w = combine_words<FB, MODE>(m.w, o.w, k.vec_need);
-        c4[i] = m;
-      }
-    }
-    __syncthreads();
-  }
-
-  // ---- phase 2: chunks of centre rows [c0+q0, c0+q0+qn); mask row j <-> grid row c0+q0-1+j
-  const int crows = c1 - c0;
+  const int n_bands = SPILL ? k.bands : 1;
   unsigned int local = 0;
-  for (int q0 = 0; q0 < crows; q0 += k.chunk_rows) {
-    const int qn = min(k.chunk_rows, crows - q0);
-    {  // 2a: activity masks, one wave per (mask row, word)
-      const int lane = tid & 63, wave = tid >> 6;
-      const int ntask = (qn + 2) * W;
-      for (int t = wave; t < ntask; t += BLOCK / 64) {
-        const int j = t / W, w = t - j * W;
-        const int g = c0 + q0 - 1 + j;                 // grid row of this mask row
-        const int x = w * 64 + lane;
-        bool on = false;
-        if (g >= t0 && g < t1 && x < k.gw)             // outside the grid = inactive
-          on = count_of<FB>(cnt, (unsigned int)((g - t0) * k.gw + x)) >= k.active_min;
-        const unsigned long long m = __ballot(on);
-        if (lane == 0) mask[(size_t)j * W + w] = m;
+  for (int band = 0; band < n_bands; ++band) {
+    // Band geometry: centres [c0,c1), tracked counter rows [t0,t1) (one halo row each side).
+    const int c0 = k.y_lo + band * k.band_rows;
+    const int c1 = min(k.y_hi, c0 + k.band_rows);
+    const int t0 = max(c0 - 1, 0);
+    const int t1 = min(c1 + 1, k.gh);
+    const int trows = t1 - t0;                 // may be <= 0 for an empty analysed range
+
+    // ---- phase 0: zero counters (and, once, the centre total and the queue tail)
+    {
+      u32x4 *c4 = reinterpret_cast<u32x4 *>(cnt);
+      const int n4 = k.cnt_words >> 2;
+      for (int i = tid; i < n4; i += BLOCK) c4[i] = (u32x4){0u, 0u, 0u, 0u};
+      if (band == 0 && tid == 0) { *total = 0u; *sq.tail = 0u; }
+    }
+    __syncthreads();
+
+    // ---- phase 1
+    if (band == 0) {                           // stream the records (HBM, exactly once per frame)
+      if (trows > 0 && k.vec_need != 0u) {     // vec_need == 0: every cell is active anyway
+        const unsigned char *base = mv + r0 * (unsigned long long)REC;
+        const unsigned long long n = r1 - r0;
+        unsigned long long i = tid;
+        constexpr unsigned long long STEP = (unsigned long long)UNROLL * BLOCK;
+        constexpr unsigned long long LAST = (unsigned long long)(UNROLL - 1) * BLOCK;
+        if constexpr ((VAR & 8) != 0) {
+          // software-pipelined: the next batch of loads is issued before this batch is consumed
+          Raw cur[UNROLL], nxt[UNROLL];
+          bool have = i + LAST < n;
+          if (have) {
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) cur[u] = load_rec<VAR, REC>(base + (i + (unsigned long long)u * BLOCK) * REC);
+          }
+          while (have) {
+            const unsigned long long j = i + STEP;
+            const bool more = j + LAST < n;
+            if (more) {
+#pragma unroll
+              for (int u = 0; u < UNROLL; ++u) nxt[u] = load_rec<VAR, REC>(base + (j + (unsigned long long)u * BLOCK) * REC);
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) vote<FB, MODE, SPILL>(decode(cur[u]), k, t0, t1, cnt, sq);
+            if (more) {
+#pragma unroll
+              for (int u = 0; u < UNROLL; ++u) cur[u] = nxt[u];
+            }
+            i = j;
+            have = more;
+          }
+        } else {
+          // main body: UNROLL independent loads in flight per lane
+          for (; i + LAST < n; i += STEP) {
+            Raw d[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) d[u] = load_rec<VAR, REC>(base + (i + (unsigned long long)u * BLOCK) * REC);
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) vote<FB, MODE, SPILL>(decode(d[u]), k, t0, t1, cnt, sq);
+          }
+        }
+        for (; i < n; i += BLOCK) vote<FB, MODE, SPILL>(decode(load_rec<VAR, REC>(base + i * REC)), k, t0, t1, cnt, sq);
+      }
+      // queue stores of every wave have left the CU before any wave of this workgroup replays them
+      if constexpr (SPILL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {                                   // replay the votes band 0 queued for later bands
+      const unsigned int nq = *sq.tail;
+      unsigned int i = (unsigned int)tid;
+      for (; i + 3u * BLOCK < nq; i += 4u * BLOCK) {
+        unsigned int e[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) e[u] = sq.q[i + (unsigned int)u * BLOCK];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int gy = (int)(e[u] >> 16), gx = (int)(e[u] & 0xffffu);
+          if (gy >= t0 && gy < t1) bump<FB, MODE>(cnt, (unsigned int)((gy - t0) * k.gw + gx), k.vec_need);
+        }
+      }
+      for (; i < nq; i += BLOCK) {
+        const unsigned int e = sq.q[i];
+        const int gy = (int)(e >> 16), gx = (int)(e & 0xffffu);
+        if (gy >= t0 && gy < t1) bump<FB, MODE>(cnt, (unsigned int)((gy - t0) * k.gw + gx), k.vec_need);
       }
     }
     __syncthreads();
-    {  // 2b: centre cells with an active 4-neighbour
-      const int ntask = qn * W;
-      for (int t = tid; t < ntask; t += BLOCK) {
-        const int r = t / W, w = t - r * W;            // centre row c0+q0+r -> mask row r+1
-        const unsigned long long *mr = mask + (size_t)(r + 1) * W;
-        const unsigned long long m = mr[w];
-        if (m == 0ull) continue;
-        const unsigned long long up = mr[w - W], dn = mr[w + W];
-        const unsigned long long lcarry = (w > 0) ? (mr[w - 1] >> 63) : 0ull;
-        const unsigned long long rcarry = (w + 1 < W) ? (mr[w + 1] << 63) : 0ull;
-        const unsigned long long nb = (m << 1) | lcarry | (m >> 1) | rcarry | up | dn;
-        // centres are x in [1, gw-2]  (:280)
-        const int lo = max(1 - w * 64, 0), hi = min(k.gw - 1 - w * 64, 64);   // bits [lo,hi)
-        unsigned long long valid = 0ull;
-        if (hi > lo) {
-          valid = (hi >= 64) ? ~0ull : ((1ull << hi) - 1ull);
-          valid &= ~((1ull << lo) - 1ull);
-        }
-        local += (unsigned int)__popcll(m & nb & valid);
+
+    // ---- slices: publish this partial grid; the LAST workgroup of the frame to arrive sums them
+    // (no workgroup ever waits for another: nothing to deadlock on).  This is the guide's
+    // Guideline 16 hand-off, recipe R1 in its counter form (MI355X_MICROARCH.md "visibility",
+    // valid-forms row "ONE lane of each storing workgroup ... an agent-scope atomic add ... the
+    // workgroup whose add came last, told by the value its add returned"):
+    //   producer  every payload byte leaves with a 16-byte WRITE-THROUGH (sc1) store: it goes
+    //             through the XCD's L2 to memory and drops the L2 line, so no release fence
+    //             (buffer_wbl2) is needed; EVERY storing wave drains (s_waitcnt vmcnt(0)); the
+    //             workgroup barrier orders all drains before ONE lane's agent-scope ticket add
+    //             (an atomic executes at the memory side, beyond the per-XCD L2s).
+    //   consumer  the last arriver learns it from the add's return value; ONE lane executes the
+    //             agent-scope acquire (buffer_inv sc1: drops this CU's L1 lines — the L1 is
+    //             shared by the CU's waves, the invalidate is not per wave) and waits for it
+    //             (vmcnt(0)); the barrier keeps every other wave's loads behind that wait; then
+    //             plain loads.  The workspace is ordinary coarse-grained device memory
+    //             (hipMallocAsync pool) that earlier launches may have cached on this CU: the
+    //             acquire is what makes those stale L1 lines unreachable.  A line of another
+    //             workgroup's tile cannot sit stale in THIS XCD's L2 from inside the launch (no
+    //             wave reads a tile before the ticket says it is complete), and lines cached by
+    //             earlier launches were dropped by the kernel-boundary invalidate.
+    // Results therefore do not depend on dispatch order or XCD placement; exercised with a warm
+    // L1 and a reused workspace by tests/test_gpu_parity.py::test_scan_frame_slices_under_load.
+    if (!SPILL && k.slices > 1) {
+      const size_t words = (size_t)k.cnt_words;
+      unsigned int *mine = slice_ws + ((size_t)f * (size_t)k.slices + (size_t)slice) * words;
+      {
+        const u32x4 *c4 = reinterpret_cast<const u32x4 *>(cnt);
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(mine, 0, k.cnt_words * 4, 0x00020000);
+        for (int i = tid; i < (k.cnt_words >> 2); i += BLOCK)
+          __builtin_amdgcn_raw_buffer_store_b128(c4[i], rsrc, i * 16, 0, /*aux: sc1*/ 16);
       }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0)
+        *ticket = __hip_atomic_fetch_add(&tickets[f], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      if (*ticket != (unsigned int)(k.slices - 1)) return;       // not the last: done
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __syncthreads();
+      for (int s2 = 0; s2 < k.slices; ++s2) {
+        if (s2 == slice) continue;
+        const u32x4 *g4 = reinterpret_cast<const u32x4 *>(slice_ws + ((size_t)f * (size_t)k.slices + (size_t)s2) * words);
+        u32x4 *c4 = reinterpret_cast<u32x4 *>(cnt);
+        for (int i = tid; i < (k.cnt_words >> 2); i += BLOCK) {
+          const u32x4 o = g4[i];
+          u32x4 m = c4[i];
+          m.x = combine_words<FB, MODE>(m.x, o.x, k.vec_need);
+          m.y = combine_words<FB, MODE>(m.y, o.y, k.vec_need);
+          m.z = combine_words<FB, MODE>(m.z, o.z, k.vec_need);
+          m.w = combine_words<FB, MODE>(m.w, o.w, k.vec_need);
+          c4[i] = m;
+        }
+      }
+      __syncthreads();
     }
-    __syncthreads();                                   // masks are rewritten by the next chunk
+
+    // ---- phase 2: chunks of centre rows [c0+q0, c0+q0+qn); mask row j <-> grid row c0+q0-1+j
+    const int crows = c1 - c0;
+    for (int q0r = 0; q0r < crows; q0r += k.chunk_rows) {
+      const int qn = min(k.chunk_rows, crows - q0r);
+      {  // 2a: activity masks, one wave per (mask row, word)
+        const int lane = tid & 63, wave = tid >> 6;
+        const int ntask = (qn + 2) * W;
+        for (int t = wave; t < ntask; t += BLOCK / 64) {
+          const int j = t / W, w = t - j * W;
+          const int g = c0 + q0r - 1 + j;                // grid row of this mask row
+          const int x = w * 64 + lane;
+          bool on = false;
+          if (g >= t0 && g < t1 && x < k.gw)             // outside the grid = inactive
+            on = count_of<FB>(cnt, (unsigned int)((g - t0) * k.gw + x)) >= k.active_min;
+          const unsigned long long m = __ballot(on);
+          if (lane == 0) mask[(size_t)j * W + w] = m;
+        }
+      }
+      __syncthreads();
+      {  // 2b: centre cells with an active 4-neighbour
+        const int ntask = qn * W;
+        for (int t = tid; t < ntask; t += BLOCK) {
+          const int r = t / W, w = t - r * W;            // centre row c0+q0r+r -> mask row r+1
+          const unsigned long long *mr = mask + (size_t)(r + 1) * W;
+          const unsigned long long m = mr[w];
+          if (m == 0ull) continue;
+          const unsigned long long up = mr[w - W], dn = mr[w + W];
+          const unsigned long long lcarry = (w > 0) ? (mr[w - 1] >> 63) : 0ull;
+          const unsigned long long rcarry = (w + 1 < W) ? (mr[w + 1] << 63) : 0ull;
+          const unsigned long long nb = (m << 1) | lcarry | (m >> 1) | rcarry | up | dn;
+          // centres are x in [1, gw-2]  (:280)
+          const int lo = max(1 - w * 64, 0), hi = min(k.gw - 1 - w * 64, 64);   // bits [lo,hi)
+          unsigned long long valid = 0ull;
+          if (hi > lo) {
+            valid = (hi >= 64) ? ~0ull : ((1ull << hi) - 1ull);
+            valid &= ~((1ull << lo) - 1ull);
+          }
+          local += (unsigned int)__popcll(m & nb & valid);
+        }
+      }
+      __syncthreads();                                   // masks / counters are rewritten next
+    }
   }
   if (local) atomicAdd(total, local);
   __syncthreads();
 
-  if (tid == 0) {
-    const unsigned int c = *total;
-    if (k.bands == 1) flags[f] = (c >= k.clust_need) ? 1 : 0;
-    else if (c) atomicAdd(&frame_centres[f], c);
-  }
-}
-
-// bands > 1: combine the per-band centre counts (one thread per frame).
-__global__ void finalize_flags_kernel(const unsigned long long *__restrict__ frame_off,
-                                      unsigned long long n_records,
-                                      const unsigned char *__restrict__ has_sd,
-                                      const unsigned int *__restrict__ frame_centres,
-                                      unsigned int n_frames, unsigned int clust_need,
-                                      unsigned char *__restrict__ flags) {
-  const unsigned int f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f >= n_frames) return;
-  unsigned long long r0 = frame_off[f], r1 = frame_off[f + 1];
-  r1 = r1 < n_records ? r1 : n_records;
-  r0 = r0 < r1 ? r0 : r1;
-  const bool sd = has_sd ? (has_sd[f] != 0) : (r1 > r0);
-  flags[f] = (sd && frame_centres[f] >= clust_need) ? 1 : 0;
+  if (tid == 0) flags[f] = (*total >= k.clust_need) ? 1 : 0;
 }
 
 // Calibration only: a pure streaming read shaped like the scan (one workgroup per contiguous
@@ -404,56 +477,56 @@ hipError_t launch_read_ceiling(const void *p, unsigned long long bytes, unsigned
 
 // ------------------------------------------------------------------ launchers
 
-template <int BLOCK, int FB, int MODE, int UNROLL = 4, int VAR = 0>
+template <int BLOCK, int FB, int MODE, int REC, bool SPILL, int UNROLL = 4, int VAR = 0>
 static hipError_t launch_one(const ScanLaunch &L) {
-  auto kern = scan_frames_kernel<BLOCK, UNROLL, FB, MODE, VAR>;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, L.lds_bytes);
-  if (e != hipSuccess) return e;
-  // bands > 1: frames are dealt in groups of 8 (same-XCD band placement), the last group is padded
-  const unsigned long long items =
-      L.k.bands > 1 ? (((unsigned long long)L.n_frames + 7ull) / 8ull) * 8ull * (unsigned long long)L.k.bands
-                    : (unsigned long long)L.n_frames * (unsigned long long)L.k.slices;
+  auto kern = scan_frames_kernel<BLOCK, UNROLL, FB, MODE, VAR, REC, SPILL>;
+  // Dynamic-LDS ceiling: set ONCE per instantiation and device to the device maximum (host
+  // threads sharing an instantiation must not race each other with per-launch values).
+  static std::atomic<unsigned long long> ready{0ull};
+  const unsigned long long bit = 1ull << (L.device & 63);
+  if ((ready.load(std::memory_order_acquire) & bit) == 0ull) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, L.lds_max);
+    if (e != hipSuccess) return e;
+    ready.fetch_or(bit, std::memory_order_release);
+  }
+  const unsigned long long items = (unsigned long long)L.n_frames * (unsigned long long)(SPILL ? 1 : L.k.slices);
   const unsigned long long chunk = L.item_chunk ? L.item_chunk : (1ull << 30);   // grid.x stays < 2^31
   for (unsigned long long i0 = 0; i0 < items; i0 += chunk) {
     const unsigned int n = (unsigned int)((items - i0 < chunk) ? (items - i0) : chunk);
     hipLaunchKernelGGL(kern, dim3(n), dim3(BLOCK), L.lds_bytes, L.stream, L.mv, L.n_records,
-                       L.frame_off, L.has_sd, (unsigned int)i0, L.n_frames, L.k, L.flags, L.frame_centres,
+                       L.frame_off, L.has_sd, (unsigned int)i0, L.n_frames, L.k, L.flags, L.spill_q,
                        L.slice_ws, L.tickets);
-    e = hipGetLastError();
+    hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
   return hipSuccess;
 }
 
-// Experiment variants of the ADD32 kernel (MTGPU_VARIANT): bit0 UNROLL 8, bit1 dwordx4 loads,
-// bit2 no nt hint, bit3 software-pipelined loop.
+// Experiment variants of the ADD32 kernel on 40-byte records (MTGPU_VARIANT): bit0 UNROLL 8,
+// bit1 dwordx4 loads, bit2 no nt hint, bit3 software-pipelined loop.
 template <int BLOCK>
 static hipError_t launch_variant(const ScanLaunch &L) {
   switch (L.variant & 15) {
-#define MT_VARIANT_CASE(v) case v: return launch_one<BLOCK, 32, MODE_ADD32, ((v) & 1) ? 8 : 4, (v)>(L);
+#define MT_VARIANT_CASE(v) case v: return launch_one<BLOCK, 32, MODE_ADD32, 40, false, ((v) & 1) ? 8 : 4, (v)>(L);
     MT_VARIANT_CASE(1) MT_VARIANT_CASE(2) MT_VARIANT_CASE(3) MT_VARIANT_CASE(4) MT_VARIANT_CASE(5)
     MT_VARIANT_CASE(6) MT_VARIANT_CASE(7) MT_VARIANT_CASE(8) MT_VARIANT_CASE(9) MT_VARIANT_CASE(10)
     MT_VARIANT_CASE(11) MT_VARIANT_CASE(12) MT_VARIANT_CASE(13) MT_VARIANT_CASE(14) MT_VARIANT_CASE(15)
 #undef MT_VARIANT_CASE
-    default: return launch_one<BLOCK, 32, MODE_ADD32>(L);
+    default: return launch_one<BLOCK, 32, MODE_ADD32, 40, false>(L);
   }
 }
 
-// Row bands re-read a frame's records (once per band): their loads use the default cache policy
-// so that the XCD's L2 keeps the lines for the sibling band (NT = false); everything else
-// streams with the nt hint (-12 % without it on single-pass reads).
-template <int BLOCK, bool NT>
-static hipError_t launch_policy(const ScanLaunch &L) {
-  constexpr int V = NT ? 0 : 4;
+template <int BLOCK, int REC, bool SPILL>
+static hipError_t launch_form(const ScanLaunch &L) {
   const int key = L.k.mode * 100 + L.k.fb;
   switch (key) {
-    case MODE_ADD32 * 100 + 32: return launch_one<BLOCK, 32, MODE_ADD32, 4, V>(L);
-    case MODE_UNARY * 100 + 1: return launch_one<BLOCK, 1, MODE_UNARY, 4, V>(L);
-    case MODE_UNARY * 100 + 2: return launch_one<BLOCK, 2, MODE_UNARY, 4, V>(L);
-    case MODE_UNARY * 100 + 4: return launch_one<BLOCK, 4, MODE_UNARY, 4, V>(L);
-    case MODE_UNARY * 100 + 8: return launch_one<BLOCK, 8, MODE_UNARY, 4, V>(L);
-    case MODE_CAS * 100 + 8: return launch_one<BLOCK, 8, MODE_CAS, 4, V>(L);
+    case MODE_ADD32 * 100 + 32: return launch_one<BLOCK, 32, MODE_ADD32, REC, SPILL>(L);
+    case MODE_UNARY * 100 + 1: return launch_one<BLOCK, 1, MODE_UNARY, REC, SPILL>(L);
+    case MODE_UNARY * 100 + 2: return launch_one<BLOCK, 2, MODE_UNARY, REC, SPILL>(L);
+    case MODE_UNARY * 100 + 4: return launch_one<BLOCK, 4, MODE_UNARY, REC, SPILL>(L);
+    case MODE_UNARY * 100 + 8: return launch_one<BLOCK, 8, MODE_UNARY, REC, SPILL>(L);
+    case MODE_CAS * 100 + 8: return launch_one<BLOCK, 8, MODE_CAS, REC, SPILL>(L);
     default: return hipErrorInvalidValue;
   }
 }
@@ -461,20 +534,20 @@ static hipError_t launch_policy(const ScanLaunch &L) {
 template <int BLOCK>
 static hipError_t launch_block(const ScanLaunch &L) {
   const int key = L.k.mode * 100 + L.k.fb;
-  if (key == MODE_ADD32 * 100 + 32 && (L.variant & 15) != 0 && BLOCK != 1024) return launch_variant<BLOCK>(L);
-  if (L.k.bands > 1 && (L.variant & 16) == 0) return launch_policy<BLOCK, false>(L);
-  return launch_policy<BLOCK, true>(L);
+  const bool spill = L.k.bands > 1;
+  if (L.rec_bytes == 40 && !spill && key == MODE_ADD32 * 100 + 32 && (L.variant & 15) != 0 && BLOCK != 1024)
+    return launch_variant<BLOCK>(L);
+  if (L.rec_bytes == 8) return spill ? launch_form<BLOCK, 8, true>(L) : launch_form<BLOCK, 8, false>(L);
+  return spill ? launch_form<BLOCK, 40, true>(L) : launch_form<BLOCK, 40, false>(L);
 }
 
 hipError_t launch_scan(const ScanLaunch &L) {
   if (L.n_frames == 0) return hipSuccess;
+  if (L.rec_bytes != 40 && L.rec_bytes != 8) return hipErrorInvalidValue;
   hipError_t e;
-  if (L.k.bands > 1) {
-    e = hipMemsetAsync(L.frame_centres, 0, sizeof(unsigned int) * (size_t)L.n_frames, L.stream);
-    if (e != hipSuccess) return e;
-  }
+  if (L.k.bands > 1 && (L.k.slices != 1 || !L.spill_q)) return hipErrorInvalidValue;
   if (L.k.slices > 1) {
-    if (L.k.bands != 1 || !L.slice_ws || !L.tickets) return hipErrorInvalidValue;
+    if (!L.slice_ws || !L.tickets) return hipErrorInvalidValue;
     e = hipMemsetAsync(L.tickets, 0, sizeof(unsigned int) * (size_t)L.n_frames, L.stream);
     if (e != hipSuccess) return e;
   }
@@ -483,13 +556,6 @@ hipError_t launch_scan(const ScanLaunch &L) {
     case 512: e = launch_block<512>(L); break;
     case 1024: e = launch_block<1024>(L); break;
     default: return hipErrorInvalidValue;
-  }
-  if (e != hipSuccess) return e;
-  if (L.k.bands > 1) {
-    const unsigned int nb = (L.n_frames + 255u) / 256u;
-    hipLaunchKernelGGL(finalize_flags_kernel, dim3(nb), dim3(256), 0, L.stream, L.frame_off,
-                       L.n_records, L.has_sd, L.frame_centres, L.n_frames, L.k.clust_need, L.flags);
-    e = hipGetLastError();
   }
   return e;
 }

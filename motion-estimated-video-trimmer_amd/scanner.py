@@ -19,8 +19,9 @@ from typing import Iterable, List, Optional, Sequence, Tuple
 import numpy as np
 
 from . import _abi, config
-from ._abi import (MERGE_PARAMS_DTYPE, MERGE_RESULT_DTYPE, MV_DTYPE, SEGMENT_DTYPE, MergeParamsC,
-                   MergeResultC, PlanC, ScanParamsC, check, load_library)
+from ._abi import (COMPACT_DTYPE, LAYOUT_AOS40, LAYOUT_COMPACT8, MERGE_PARAMS_DTYPE, MERGE_RESULT_DTYPE,
+                   MV_DTYPE, SEGMENT_DTYPE, MergeParamsC, MergeResultC, PlanC, ScanParamsC, check,
+                   load_library)
 
 
 @dataclass
@@ -158,6 +159,16 @@ def _ptr(a: Optional[np.ndarray]):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+def pack_records(mv: np.ndarray) -> np.ndarray:
+    """40-byte AVMotionVector records -> the 8-byte compact records the host dispatcher stages
+    (bytes 6..13: src_x, src_y, dst_x, dst_y) through the library's own packer (mtgpu_pack_records)."""
+    mv = np.ascontiguousarray(mv, dtype=MV_DTYPE)
+    out = np.zeros(len(mv), dtype=COMPACT_DTYPE)
+    if len(mv):
+        check(load_library().mtgpu_pack_records(_ptr(mv), len(mv), _ptr(out)))
+    return out
+
+
 class MotionScanner:
     """GPU scanner context (one per device; callable from many threads)."""
 
@@ -234,6 +245,24 @@ class MotionScanner:
             None if has_sd is None else has_sd.data_ptr(), n_frames, flags.data_ptr(), st))
         return flags
 
+    def check_frames_device_compact(self, rec8, frame_off, has_sd=None, flags=None, stream=None):
+        """Device-resident batch of COMPACT records (8 bytes each, see pack_records): rec8 is a
+        torch CUDA tensor viewing n_records * 8 bytes.  Otherwise like check_frames_device."""
+        import torch
+        n_frames = frame_off.numel() - 1
+        if flags is None:
+            flags = torch.empty(max(n_frames, 0), dtype=torch.uint8, device=frame_off.device)
+        if n_frames <= 0:
+            return flags
+        assert rec8.is_contiguous() and frame_off.is_contiguous() and flags.is_contiguous()
+        assert frame_off.dtype == torch.int64 and flags.dtype == torch.uint8
+        n_records = (rec8.numel() * rec8.element_size()) // 8
+        st = torch.cuda.current_stream(frame_off.device).cuda_stream if stream is None else stream
+        check(self._lib.mtgpu_scan_frames_device_compact(
+            self._ctx, rec8.data_ptr() if n_records else None, n_records, frame_off.data_ptr(),
+            None if has_sd is None else has_sd.data_ptr(), n_frames, flags.data_ptr(), st))
+        return flags
+
     def scan_range(self, frame_pts: Sequence[int], frames: Sequence[Optional[np.ndarray]],
                    time_base: float, start: float, end: float, video_fps: float,
                    target_fps: Optional[float] = None) -> List[float]:
@@ -304,12 +333,15 @@ class ScanPipe:
     staging and submits full batches asynchronously; drain() returns every finished
     (pts, flag, tag) in submission order."""
 
-    def __init__(self, scanner: MotionScanner, max_records: int, max_frames: int, n_buffers: int = 3):
+    def __init__(self, scanner: MotionScanner, max_records: int, max_frames: int, n_buffers: int = 3,
+                 layout: int = LAYOUT_COMPACT8):
+        """layout: LAYOUT_COMPACT8 (default; 8 of every 40 record bytes are staged and shipped)
+        or LAYOUT_AOS40 (records staged unchanged).  Results are identical."""
         self._lib = scanner._lib
         self._scanner = scanner            # keeps the context alive
         self._pipe = C.c_void_p()
-        check(self._lib.mtgpu_pipe_create(scanner._ctx, int(max_records), int(max_frames), int(n_buffers),
-                                          C.byref(self._pipe)))
+        check(self._lib.mtgpu_pipe_create_layout(scanner._ctx, int(max_records), int(max_frames),
+                                                 int(n_buffers), int(layout), C.byref(self._pipe)))
         self._cur = None
         self._inflight = 0
         self._done: List[Tuple[float, int, int]] = []

@@ -53,8 +53,10 @@ int mto_params_from_config(mt_scan_params *out, int width, int height,
 /* ------------------------------------------------------------ a3..a5 --- */
 
 static int params_ok(const mt_scan_params *p) {
+  /* vertical_margin < 0 (a negative VERTICAL_MASK) makes the reference index before the grid
+   * (:237, :285): outside the defined domain, rejected like the product does (validate_params). */
   return p && p->grid_w >= 1 && p->grid_h >= 1 && p->grid_w <= 32767 && p->grid_h <= 32767 &&
-         p->block_shift >= 0 && p->block_shift <= 31;
+         p->block_shift >= 0 && p->block_shift <= 31 && p->vertical_margin >= 0;
 }
 
 /* Phase 1, motion_scanner.cpp:229-268. */

@@ -1,0 +1,511 @@
+"""GPU tier, part 2 (`-m gpu`): the committed golden fixtures and BASELINE.json's multi-stream /
+multi-GPU configurations DIRECTLY through the HIP path (C ABI of libmtgpu.so).
+
+  * tests/golden/check_frame_hand_cases.json   -> mtgpu_scan_frames, every counter form, both
+                                                  record layouts (40-byte AoS, 8-byte compact)
+  * tests/golden/merge_hand_cases.json         -> mtgpu_merge_segments / mtgpu_merge_streams_device
+  * tests/golden/survey_segments.json          -> mtgpu_merge_segments, 17-digit prints
+  * tests/golden/frame_filter_hand_cases.json  -> Python host mirror + C++ GpuMotionScanner
+  * config 4 (64 concurrent 1080p streams)     -> scan -> merge_streams_device -> pack ->
+                                                  mtgpu_gather_segments, per-stream vs the oracle
+  * time-range split of one stream at world 2 / 8 (ranks simulated one after the other)
+  * extract_mvs JSON front end (mvjson)        -> HIP scan
+"""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import mvtrim_amd as m
+from mvtrim_amd import dist as mdist
+from mvtrim_amd import synth
+
+import oracle_binding as ob
+from golden_cases import (build_mvs, id_of, load_filter_cases, load_hand_cases, load_merge_cases,
+                          load_survey_segments, merge_case_ts)
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def scan_compact(scanner, mv, off, has_sd):
+    """Frames through the compact-record entry point: library packer -> device -> REC 8 kernel."""
+    import torch
+    rec = m.pack_records(mv)
+    d_rec = torch.from_numpy(rec.view(np.uint8).reshape(-1).copy()).cuda() if len(rec) else \
+        torch.zeros(8, dtype=torch.uint8, device="cuda")
+    d_off = torch.from_numpy(np.ascontiguousarray(off, dtype=np.uint64).astype(np.int64)).cuda()
+    d_sd = None if has_sd is None else torch.from_numpy(np.ascontiguousarray(has_sd, dtype=np.uint8)).cuda()
+    got = scanner.check_frames_device_compact(d_rec[: len(rec) * 8], d_off, d_sd)
+    torch.cuda.synchronize()
+    return got.cpu().numpy()
+
+
+# ------------------------------------------------------------------ check_frame hand cases
+
+@pytest.mark.parametrize("force_fb", [None, 2, 8, 108])
+@pytest.mark.parametrize("name,kw,case", load_hand_cases()[1], ids=id_of)
+def test_check_frame_hand_cases_on_gpu(gpu_scanner_factory, name, kw, case, force_fb):
+    """Every hand-derived known answer (reference src/motion_scanner.cpp:217-295) through
+    mtgpu_scan_frames: 32-bit add counters (None), 2-/8-bit thermometer fields, 8-bit CAS fields."""
+    p = m.ScanParams.from_config(**kw)
+    s = gpu_scanner_factory(p, force_fb=force_fb)
+    if force_fb is not None:
+        assert s.plan["counter_bits"] == force_fb % 100
+    mv = build_mvs(case)
+    sd = int(case.get("has_sd", 1))
+    b = m.FrameBatch.from_frames([mv if sd else None])
+    if not sd:                                         # "no side data whatever the records": keep the records
+        b = m.FrameBatch(mv, np.array([0, len(mv)], dtype=np.uint64), None, np.zeros(1, dtype=np.uint8))
+    got = s.check_frames(b)
+    assert got.tolist() == [case["expect"]], name
+    assert scan_compact(s, b.mv, b.frame_off, b.has_sd).tolist() == [case["expect"]], name
+    if len(mv) > 1:                                    # record order must not matter
+        b2 = m.FrameBatch(mv[::-1].copy(), b.frame_off, None, b.has_sd)
+        assert s.check_frames(b2).tolist() == [case["expect"]]
+
+
+def test_check_frame_hand_cases_one_batch(gpu_scanner_factory):
+    """All cases that share the base parameters in ONE batch (frames of very different sizes
+    side by side, incl. empty and side-data-less ones), sliced and unsliced."""
+    g, cases = load_hand_cases()
+    base = [(n, c) for n, kw, c in cases if kw == g["base"]]
+    assert len(base) >= 15
+    p = m.ScanParams.from_config(**g["base"])
+    frames = [build_mvs(c) if int(c.get("has_sd", 1)) else None for _, c in base]
+    want = [c["expect"] if int(c.get("has_sd", 1)) else 0 for _, c in base]
+    b = m.FrameBatch.from_frames(frames)
+    for slices in (1, 4):
+        s = gpu_scanner_factory(p)
+        s.set_slices(slices)
+        assert s.check_frames(b).tolist() == want
+        assert scan_compact(s, b.mv, b.frame_off, b.has_sd).tolist() == want
+
+
+# ------------------------------------------------------------------ merge hand cases
+
+@pytest.mark.parametrize("name,kw,case", load_merge_cases(), ids=id_of)
+def test_merge_hand_cases_on_gpu(gpu_scanner_factory, name, kw, case):
+    """Hand-derived merge / clamp / savings / decision answers (src/pipeline.cpp:302-358, 387-388)
+    through mtgpu_merge_segments and mtgpu_merge_streams_device: exact doubles."""
+    import torch
+    s = gpu_scanner_factory(m.ScanParams.from_config(1920, 1080))
+    ts = merge_case_ts(case)
+    mp = m.MergeParams(**kw)
+    seg, res = s.merge_segments(ts, mp, False)
+    assert [list(x) for x in seg.tolist()] == case["segments"]
+    assert res["time_removed"] == case["time_removed"] and res["do_cut"] == case["do_cut"]
+    if "n_unique" in case:
+        assert res["n_timestamps"] == case["n_unique"]
+    job, jres = s.merge_segments(ts, mp, True)
+    assert [list(x) for x in job.tolist()] == case["job"] and jres["n_segments"] == len(case["job"])
+    # the device-resident stream entry point: the timestamps as one stream of all-flagged frames
+    n = len(ts)
+    d_pts = torch.tensor(ts if n else [0.0], dtype=torch.float64, device="cuda")
+    d_fl = torch.ones(max(n, 1), dtype=torch.uint8, device="cuda")
+    if n == 0:
+        d_fl.zero_()
+    soff = torch.tensor([0, max(n, 1)], dtype=torch.int64, device="cuda")
+    d_mp = torch.from_numpy(mp.to_record().view(np.uint8).copy()).cuda()
+    dseg, dres = s.merge_streams_device(d_fl, d_pts, soff, d_mp, job_semantics=True, seg_cap=128)
+    torch.cuda.synchronize()
+    rec = m.results_from_bytes(dres.cpu().numpy())[0]
+    k = int(rec["n_segments"])
+    assert k == len(case["job"]) and int(rec["do_cut"]) == case["do_cut"]
+    assert dseg[0, :k].cpu().numpy().tolist() == case["job"]
+    assert float(rec["time_removed"]) == case["time_removed"]
+
+
+def test_merge_reproduces_survey_recorded_segments_on_gpu(gpu_scanner_factory):
+    """tests/golden/survey_segments.json: the two FFmpegJob segments SURVEY.md section 8c recorded
+    from a run of the reference's object code; the device merge prints the same 17 digits."""
+    s = gpu_scanner_factory(m.ScanParams.from_config(1920, 1080))
+    g, ts, mp = load_survey_segments()
+    for order in (ts, ts[::-1], list(np.random.RandomState(1).permutation(ts))):
+        seg, res = s.merge_segments(order, mp, True)
+        assert res["do_cut"] == 1
+        assert [["%.17g" % a, "%.17g" % b] for a, b in seg.tolist()] == g["segments_printed_17g"]
+
+
+# ------------------------------------------------------------------ a6 / a7 hand cases
+
+def _filter_golden_stream(tmp_path):
+    """The `pipeline` case of frame_filter_hand_cases.json as an .mtmv file: 100 frames at
+    pts i/32 (time_base 1/64), keyframes without side data at 0/20/50, every other frame with a
+    strong 2x2-cell cluster."""
+    g = load_filter_cases()
+    pl = g["pipeline"]
+    frames = []
+    for i in range(pl["n_frames"]):
+        if i in pl["keyframes"]:
+            frames.append(None)
+            continue
+        mv = np.zeros(8, dtype=m.MV_DTYPE)
+        mv["dst_x"] = [168, 168, 184, 184, 168, 168, 184, 184]
+        mv["dst_y"] = [120, 120, 120, 120, 136, 136, 136, 136]
+        mv["src_x"] = mv["dst_x"] - 9
+        mv["src_y"] = mv["dst_y"]
+        mv["w"], mv["h"], mv["motion_scale"], mv["source"] = 16, 16, 4, -1
+        frames.append(mv)
+    ticks = [g["ticks_per_frame"] * i for i in range(pl["n_frames"])]
+    path = str(tmp_path / "filter.mtmv")
+    m.mvfile.write_mtmv(path, 320, 240, 1, g["time_base_den"], pl["fps"], pl["duration"], ticks, frames)
+    return g, pl, frames, ticks, path
+
+
+def test_frame_filter_hand_cases_python_host(gpu_scanner_factory, tmp_path):
+    """MotionScanner.scan_range (Python host mirror + HIP check_frame) on the hand-derived
+    whole-video case: chunk by chunk, then pooled."""
+    g, pl, frames, ticks, _ = _filter_golden_stream(tmp_path)
+    s = gpu_scanner_factory(m.ScanParams.from_config(320, 240))
+    tb = 1.0 / g["time_base_den"]
+    pooled = []
+    for k, (c0, c1, _) in enumerate(m.make_chunks(pl["duration"], pl["chunk_sec"])):
+        target = int(c0 / tb)
+        first = max(f for f in pl["keyframes"] if ticks[f] <= target) if c0 > 0 else 0
+        got = s.scan_range(ticks[first:], frames[first:], tb, c0, c1, pl["fps"], target_fps=pl["target_fps"])
+        assert got == [f / 32.0 for f in pl["per_chunk"][k] if f not in pl["keyframes"]]
+        pooled += got
+    assert pooled == [f / 32.0 for f in pl["timestamps_frames"]]
+
+
+@pytest.mark.parametrize("staging", ["compact8", "aos40"])
+def test_frame_filter_hand_cases_cpp_host(tmp_path, staging):
+    """The same case through the C++ host layer (GpuMotionScanner::scan_range, chunk workers,
+    MtmvSource's backward seek): pooled timestamps == the hand-derived list, any worker count."""
+    g, pl, frames, ticks, path = _filter_golden_stream(tmp_path)
+    exe = os.path.join(os.path.dirname(m.LIB_PATH), "mtgpu_scan_file")
+    env = dict(os.environ, CHUNK_DURATION_SEC=str(pl["chunk_sec"]), TARGET_FPS=str(pl["target_fps"]),
+               MAX_GAP_SEC="5.0", PADDING_SEC="0.5", MIN_SAVINGS_PCT="5", MTGPU_STAGING=staging)
+    for k in ("VECTORS_NEEDED", "CLUSTERS_NEEDED", "MV_THRESHOLD_SQ", "BLOCK_SIZE", "BLOCK_SHIFT", "VERTICAL_MASK"):
+        env.pop(k, None)
+    for threads in (1, 2, 3):
+        out = subprocess.run([exe, path, "--threads", str(threads), "--timestamps"], check=True,
+                             capture_output=True, text=True, env=env).stdout
+        r = json.loads(out)
+        assert r["chunks"] == 3
+        assert r["timestamps"] == [f / 32.0 for f in pl["timestamps_frames"]]
+        # one segment: first 2/32 - 0.5 -> clamped to 0, last 94/32 + 0.5 -> clamped to duration 3.0
+        assert r["segments"] == [[0.0, 3.0]] and r["do_cut"] == 0
+
+
+# ------------------------------------------------------------------ config 4: 64 concurrent 1080p streams
+
+def _gen_streams(n_streams, n_frames, seed0):
+    """n_streams distinct-seed 1080p dense8x8 streams, each with its own scripted events."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    def one(i):
+        spec = synth.spec_1080p(seed=seed0 + i, sub=2, gop=16, salt_p=0.0 if i % 16 == 5 else 1e-3)
+        rng = np.random.RandomState(seed0 + i)
+        ev, f = [], int(rng.randint(1, 6))
+        while f < n_frames:                                # short bursts, gaps on both sides of max_gap
+            ln = int(rng.randint(1, 5))
+            ev.append(synth.Event(f, min(n_frames, f + ln), int(rng.randint(2, 100)), int(rng.randint(8, 50)),
+                                  int(rng.randint(2, 6)), int(rng.randint(2, 5)), int(rng.choice([-9, 7, 12])), 2))
+            f += ln + int(rng.choice([2, 3, 9, 14]))
+        if i % 16 == 5:
+            ev = []                                        # a still stream: no motion at all
+        spec.events = ev
+        return spec, synth.gen_stream(spec, n_frames)
+
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        return list(ex.map(one, range(n_streams)))
+
+
+def test_config4_64_streams_scan_merge_gather(gpu_scanner_factory):
+    """BASELINE.json config 4 on one GPU: 64 distinct-seed 1080p dense8x8 streams in one device
+    batch -> mtgpu_scan_frames_device -> mtgpu_merge_streams_device -> pack_segment_lists ->
+    1-rank mtgpu_gather_segments (RCCL) -> per-stream bit-compare with the oracle.  Then the same
+    streams as 8 ranks x 8 streams (ranks run one after the other on this GPU, their packed blocks
+    concatenated rank-major exactly as the all-gather delivers them)."""
+    import ctypes as C
+    import torch
+    S, F, CAP = 64, 32, 32
+    streams = _gen_streams(S, F, seed0=4000)
+    p = ob.params_from_config(1920, 1080)
+    s = gpu_scanner_factory(m.ScanParams.from_config(1920, 1080))
+    mv = np.concatenate([st[1][0] for st in streams])
+    counts = np.concatenate([np.diff(st[1][1].astype(np.int64)) for st in streams])
+    off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    pts = np.concatenate([st[1][2] for st in streams])
+    sd = np.concatenate([st[1][3] for st in streams])
+    mps = [m.MergeParams(duration=F / 30.0, max_gap_sec=0.2, padding_sec=0.05, min_savings_pct=5.0) for _ in range(S)]
+    want_flags = ob.scan_frames(p, mv, off.astype(np.uint64), sd, nthreads=8)
+    assert 0.1 < want_flags.mean() < 0.9
+
+    d_mv = torch.from_numpy(mv.view(np.uint8).reshape(-1)).cuda()
+    d_off = torch.from_numpy(off).cuda()
+    d_sd = torch.from_numpy(sd).cuda()
+    d_pts = torch.from_numpy(pts).cuda()
+    soff = torch.from_numpy(np.arange(S + 1, dtype=np.int64) * F).cuda()
+    d_mp = torch.from_numpy(np.concatenate([x.to_record() for x in mps]).view(np.uint8).copy()).cuda()
+    flags = s.check_frames_device(d_mv, d_off, d_sd)
+    seg, res = s.merge_streams_device(flags, d_pts, soff, d_mp, job_semantics=True, seg_cap=CAP)
+    torch.cuda.synchronize()
+    assert np.array_equal(flags.cpu().numpy(), want_flags)
+    packed = mdist.pack_segment_lists(seg, res)
+
+    lib = m.load_library()
+    uid = (C.c_char * 128)()
+    m._abi.check(lib.mtgpu_comm_unique_id(uid))
+    comm = C.c_void_p()
+    m._abi.check(lib.mtgpu_comm_create(0, 1, uid, 0, C.byref(comm)))
+    try:
+        recv = torch.zeros((1,) + tuple(packed.shape), dtype=torch.uint8, device="cuda")
+        m._abi.check(lib.mtgpu_gather_segments(comm, packed.data_ptr(), packed.numel(), recv.data_ptr(),
+                                               torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+    finally:
+        lib.mtgpu_comm_destroy(comm)
+    lists = mdist.assemble_stream_lists(recv, CAP, [S])
+
+    def check_lists(lists):
+        assert len(lists) == S
+        n_cut = n_still = 0
+        for i, ent in enumerate(lists):
+            a, b = i * F, (i + 1) * F
+            want_seg, want_res = ob.pool_and_merge(pts[a:b][want_flags[a:b] != 0], mps[i], True)
+            r = ent["result"]
+            assert int(r["status"]) == 0 and int(r["n_timestamps"]) == want_res["n_timestamps"], i
+            assert int(r["n_segments"]) == want_res["n_segments"] and int(r["do_cut"]) == want_res["do_cut"], i
+            assert np.array_equal(bits(ent["segments"][:, 0]), bits(want_seg["start"])), i
+            assert np.array_equal(bits(ent["segments"][:, 1]), bits(want_seg["end"])), i
+            assert bits([r["time_removed"], r["saved_pct"]]).tolist() == \
+                bits([want_res["time_removed"], want_res["saved_pct"]]).tolist(), i
+            n_cut += int(r["do_cut"]) == 1
+            n_still += int(r["do_cut"]) == -1
+        assert n_cut >= 32 and n_still == 4
+    check_lists(lists)
+
+    # 8 ranks x 8 streams: every rank scans + merges only its own streams' frames
+    blocks = []
+    for rank in range(8):
+        a, b = mdist.shard_range(S, 8, rank)
+        fa, fb = a * F, b * F
+        ra, rb = int(off[fa]), int(off[fb])
+        r_off = torch.from_numpy(off[fa:fb + 1] - off[fa]).cuda()
+        r_flags = s.check_frames_device(d_mv[ra * 40: rb * 40], r_off, d_sd[fa:fb])
+        r_soff = torch.from_numpy(np.arange(b - a + 1, dtype=np.int64) * F).cuda()
+        r_seg, r_res = s.merge_streams_device(r_flags, d_pts[fa:fb], r_soff, d_mp[a * 32: b * 32].contiguous(),
+                                              job_semantics=True, seg_cap=CAP)
+        blocks.append(mdist.pack_segment_lists(r_seg, r_res))
+    gathered = torch.stack(blocks)                                # [world, S/world, cap*16+40]: rank-major
+    torch.cuda.synchronize()
+    check_lists(mdist.assemble_stream_lists(gathered, CAP, [8] * 8))
+
+
+# ------------------------------------------------------------------ time-range split of one stream
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_timerange_split_world_simulated(gpu_scanner_factory, world):
+    """One stream cut into `world` contiguous frame ranges of ~equal record counts
+    (dist.shard_by_records); every range is scanned by the HIP path as its rank would, the ranks'
+    timestamps are pooled rank-major (what gather_timestamps returns) and merged ONCE: segments
+    bit-identical to the whole-stream result and to the oracle (src/pipeline.cpp:302-356)."""
+    import torch
+    spec = synth.spec_1080p(seed=77, sub=2)
+    n = 240
+    spec.events = synth.scripted_events(spec, n) + [synth.Event(100, 130, 50, 30, 4, 4, 9, 1)]
+    mv, off, pts, sd = synth.gen_stream(spec, n)
+    p = ob.params_from_config(1920, 1080)
+    s = gpu_scanner_factory(m.ScanParams.from_config(1920, 1080))
+    mp = m.MergeParams(duration=n / 30.0, max_gap_sec=1.0, padding_sec=0.25, min_savings_pct=5.0)
+    want_flags = ob.scan_frames(p, mv, off, sd, nthreads=8)
+    want_seg, want_res = ob.pool_and_merge(pts[want_flags != 0], mp, True)
+    assert want_res["n_segments"] >= 2
+
+    d_mv = torch.from_numpy(mv.view(np.uint8).reshape(-1)).cuda()
+    off64 = off.astype(np.int64)
+    pooled, got_flags = [], []
+    for (a, b) in mdist.shard_by_records(off64, world):
+        if b == a:
+            continue
+        ra, rb = int(off64[a]), int(off64[b])
+        fl = s.check_frames_device(d_mv[ra * 40: rb * 40], torch.from_numpy(off64[a:b + 1] - off64[a]).cuda(),
+                                   torch.from_numpy(sd[a:b]).cuda()).cpu().numpy()
+        got_flags.append(fl)
+        pooled.append(pts[a:b][fl != 0])
+    assert np.array_equal(np.concatenate(got_flags), want_flags)
+    ts = np.concatenate(pooled[::-1])                      # any rank order: the merge sorts
+    seg, res = s.merge_segments(ts, mp, True)
+    assert seg.tobytes() == want_seg.tobytes()
+    assert res["do_cut"] == want_res["do_cut"] and res["n_timestamps"] == want_res["n_timestamps"]
+    assert bits([res["time_removed"], res["saved_pct"]]).tolist() == \
+        bits([want_res["time_removed"], want_res["saved_pct"]]).tolist()
+    # and identical to the whole stream scanned + merged on the device in one go
+    fl_all = s.check_frames_device(d_mv, torch.from_numpy(off64).cuda(), torch.from_numpy(sd).cuda())
+    dseg, dres = s.merge_streams_device(fl_all, torch.from_numpy(pts).cuda(),
+                                        torch.tensor([0, n], dtype=torch.int64, device="cuda"),
+                                        torch.from_numpy(mp.to_record().view(np.uint8).copy()).cuda(), True, 64)
+    torch.cuda.synchronize()
+    k = int(m.results_from_bytes(dres.cpu().numpy())[0]["n_segments"])
+    assert dseg[0, :k].cpu().numpy().tobytes() == np.stack([want_seg["start"], want_seg["end"]], 1).tobytes()
+
+
+# ------------------------------------------------------------------ f2: extract_mvs JSON -> HIP scan
+
+def test_mvjson_roundtrip_feeds_the_hip_scan(gpu_scanner_factory, tmp_path):
+    """write_json -> read_json (schema of tools/extract_mvs.cpp:97-169) -> mtgpu_scan_frames:
+    same flags as the direct-record scan and as the oracle; likewise through the .mtmv container."""
+    spec = synth.StreamSpec(width=640, height=480, block=16, sub=2, fps=25.0, gop=10, seed=31)
+    spec.events = [synth.Event(2, 14, 10, 8, 4, 3, 9, -4), synth.Event(20, 28, 25, 15, 3, 3, -7, 2)]
+    n = 30
+    frames = [synth.gen_frame(spec, i) for i in range(n)]
+    pts = [spec.pts_seconds(i) for i in range(n)]
+    p = ob.params_from_config(640, 480)
+    s = gpu_scanner_factory(m.ScanParams.from_config(640, 480))
+    b0 = m.FrameBatch.from_frames(frames)
+    want = ob.scan_frames(p, b0.mv, b0.frame_off, b0.has_sd)
+    assert 0 < want.sum() < n
+    direct = s.check_frames(b0)
+    assert np.array_equal(direct, want)
+    js = str(tmp_path / "s.json")
+    m.mvjson.write_json(js, frames, pts, (1, 90000))
+    f2, p2, tb = m.mvjson.read_json(js)
+    b2 = m.FrameBatch.from_frames(f2)
+    assert np.array_equal(s.check_frames(b2), want)
+    assert np.array_equal(scan_compact(s, b2.mv, b2.frame_off, b2.has_sd), want)
+    # the timestamps the JSON carries (%.6f seconds) merge to the oracle's segments for those values
+    mp = m.MergeParams(duration=n / 25.0, max_gap_sec=0.2, padding_sec=0.1, min_savings_pct=5.0)
+    ts = [t for t, f in zip(p2, want) if f]
+    seg, res = s.merge_segments(ts, mp, True)
+    wseg, wres = ob.pool_and_merge(ts, mp, True)
+    assert seg.tobytes() == wseg.tobytes() and res["do_cut"] == wres["do_cut"]
+    mt = str(tmp_path / "s.mtmv")
+    m.mvfile.write_mtmv(mt, 640, 480, 1, 90000, 25.0, n / 25.0, [spec.pts_ticks(i) for i in range(n)], frames)
+    _, tab, mv = m.mvfile.read_mtmv(mt)
+    b1 = m.FrameBatch.from_frames(m.mvfile.frames_of(tab, mv))
+    assert np.array_equal(s.check_frames(b1), want)
+
+
+# ------------------------------------------------------------------ compact records + host dispatcher
+
+def test_compact_records_match_aos_everywhere(gpu_scanner_factory):
+    """The 8-byte compact layout (what the host dispatcher ships) gives the flags of the 40-byte
+    layout for every counter form, for banded and sliced plans and on ragged adversarial frames."""
+    rng = np.random.RandomState(99)
+    cases = [(1920, 1080, dict(), None, 0), (1920, 1080, dict(vectors_needed=3), 4, 0),
+             (1920, 1080, dict(vectors_needed=9), 108, 2), (3840, 2160, dict(), None, 0),
+             (3840, 2160, dict(block_size=4, block_shift=2, vectors_needed=1), None, 4),
+             (3840, 2160, dict(block_size=4, block_shift=2, vectors_needed=4), None, 0),     # row bands (spill queue)
+             (3840, 2160, dict(block_size=4, block_shift=2, vectors_needed=1), 32, 0),       # many row bands
+             (1000, 600, dict(block_size=1, block_shift=0, vectors_needed=2, vertical_mask=0.0), None, 0)]
+    for (w, h, kw, fb, slices) in cases:
+        p = ob.params_from_config(w, h, **kw)
+        s = gpu_scanner_factory(m.ScanParams.from_config(w, h, **kw), force_fb=fb)
+        if slices:
+            s.set_slices(slices)
+        mv, off, sd = synth.random_frames(rng, 20, 6000, w, h, hot=0.5)
+        want = ob.scan_frames(p, mv, off, sd)
+        assert np.array_equal(s.check_frames(m.FrameBatch(mv, off, None, sd)), want), (w, h, kw, fb)
+        assert np.array_equal(scan_compact(s, mv, off, sd), want), (w, h, kw, fb, s.plan)
+        assert np.array_equal(scan_compact(s, mv, off, None), ob.scan_frames(p, mv, off, None))
+
+
+@pytest.mark.parametrize("layout", [m.LAYOUT_COMPACT8, m.LAYOUT_AOS40])
+def test_scan_pipe_layouts_and_oversize_frames(gpu_scanner_factory, layout):
+    """Both staging layouts of the pinned pipe against the oracle, including a frame larger than a
+    whole batch (the reference's check_frame accepts any record count: the pipe grows the batch)."""
+    spec = synth.spec_1080p(seed=17, sub=1)
+    spec.events = synth.scripted_events(spec, 90)
+    frames = [synth.gen_frame(spec, i) for i in range(90)]
+    frames[7] = np.zeros(0, dtype=m.MV_DTYPE)
+    big = synth.gen_frame(synth.spec_1080p(seed=18, sub=2), 5)          # 32 640 records among 8 160-record frames
+    frames[40] = big
+    p = ob.params_from_config(1920, 1080, vectors_needed=1)
+    s = gpu_scanner_factory(m.ScanParams.from_config(1920, 1080, vectors_needed=1))
+    b = m.FrameBatch.from_frames(frames)
+    want = ob.scan_frames(p, b.mv, b.frame_off, b.has_sd)
+    for (max_rec, max_fr, nbuf) in [(8160 * 5, 7, 2), (8160, 1, 1), (100, 4, 2), (8160 * 3 + 17, 1000, 4)]:
+        pipe = m.ScanPipe(s, max_rec, max_fr, nbuf, layout=layout)
+        for i, f in enumerate(frames):
+            pipe.feed(f, spec.pts_seconds(i), tag=i)
+        out = pipe.drain()
+        assert [t for _, _, t in out] == list(range(90))
+        assert [fl for _, fl, _ in out] == want.tolist(), (max_rec, max_fr, nbuf)
+        pipe.close()
+
+
+def test_pipe_submit_failure_leaves_batches_usable(gpu_scanner_factory, monkeypatch):
+    """State machine under an injected failure (MTGPU_INJECT_SUBMIT_FAIL: the 2nd submit fails
+    after its H2D copies were queued): the call reports the error, the batch is still being filled
+    (re-submit works), nothing leaks: the pipe finishes the stream with correct flags."""
+    import ctypes as C
+    spec = synth.spec_1080p(seed=23, sub=1)
+    spec.events = synth.scripted_events(spec, 40)
+    frames = [synth.gen_frame(spec, i) for i in range(40)]
+    p = ob.params_from_config(1920, 1080, vectors_needed=1)
+    s = gpu_scanner_factory(m.ScanParams.from_config(1920, 1080, vectors_needed=1))
+    b = m.FrameBatch.from_frames(frames)
+    want = ob.scan_frames(p, b.mv, b.frame_off, b.has_sd)
+    monkeypatch.setenv("MTGPU_INJECT_SUBMIT_FAIL", "2")
+    pipe = m.ScanPipe(s, 8160 * 4, 4, 2)
+    monkeypatch.delenv("MTGPU_INJECT_SUBMIT_FAIL")
+    lib = m.load_library()
+    failures = 0
+    for i, f in enumerate(frames):
+        try:
+            pipe.feed(f, spec.pts_seconds(i), tag=i)
+        except m.MtgpuError as e:
+            assert e.code == 3 and "injected" in str(e)
+            failures += 1
+            # the failed batch is still in state "filling": submit it again, then feed the frame
+            m._abi.check(lib.mtgpu_pipe_submit(pipe._pipe, pipe._cur))
+            pipe._cur = None
+            pipe._inflight += 1
+            pipe.feed(f, spec.pts_seconds(i), tag=i)
+    assert failures == 1
+    out = pipe.drain()
+    assert [t for _, _, t in out] == list(range(40)) and [fl for _, fl, _ in out] == want.tolist()
+    # every staging batch is free again
+    held = []
+    for _ in range(2):
+        h = C.c_void_p()
+        m._abi.check(lib.mtgpu_pipe_acquire(pipe._pipe, C.byref(h)))
+        held.append(h)
+    assert lib.mtgpu_pipe_acquire(pipe._pipe, C.byref(C.c_void_p())) == m._abi.MT_ERR_BUSY
+    for h in held:
+        m._abi.check(lib.mtgpu_pipe_release(pipe._pipe, h))
+    pipe.close()
+
+
+def _fine_stream_file(tmp_path, n):
+    spec = synth.StreamSpec(width=3840, height=2160, block=4, sub=1, fps=30.0, gop=12, seed=61, salt_p=1e-4)
+    spec.events = [synth.Event(3, 9, 300, 200, 8, 6, 9, 3), synth.Event(20, 26, 500, 100, 5, 5, -7, 0)]
+    frames = [synth.gen_frame(spec, i) for i in range(n)]
+    ticks = [spec.pts_ticks(i) for i in range(n)]
+    path = str(tmp_path / "fine.mtmv")
+    m.mvfile.write_mtmv(path, 3840, 2160, 1, spec.tb_den, spec.fps, n / spec.fps, ticks, frames)
+    return spec, frames, ticks, path
+
+
+def test_cpp_host_pipeline_4k_fine_and_failure_exit_code(tmp_path):
+    """mtgpu_scan_file on a 4K / 4x4-block stream (518 400 records per frame: far beyond the old
+    fixed 131 072-record batch) against the oracle-driven transcription of the reference's worker
+    loop; and a failing scan must exit non-zero with the error on stderr (never rc 0 with partial
+    segments)."""
+    from test_gpu_parity import _check_job, _reference_worker_loop
+    exe = os.path.join(os.path.dirname(m.LIB_PATH), "mtgpu_scan_file")
+    n = 36
+    spec, frames, ticks, path = _fine_stream_file(tmp_path, n)
+    cfg = dict(BLOCK_SIZE="4", BLOCK_SHIFT="2", VECTORS_NEEDED="1", CHUNK_DURATION_SEC="0.5", TARGET_FPS="0",
+               MAX_GAP_SEC="0.2", PADDING_SEC="0.1", MIN_SAVINGS_PCT="5")
+    env = dict(os.environ, **cfg)
+    p = ob.params_from_config(3840, 2160, block_size=4, block_shift=2, vectors_needed=1)
+    mp = m.MergeParams(duration=n / spec.fps, max_gap_sec=0.2, padding_sec=0.1, min_savings_pct=5.0)
+    pooled, (want_seg, want_res) = _reference_worker_loop(spec, frames, ticks, n / spec.fps, p, 0.5, 0.0, mp)
+    assert len(pooled) >= 8 and len(want_seg) >= 2
+    for staging in ("compact8", "aos40"):
+        out = subprocess.run([exe, path, "--threads", "2"], check=True, capture_output=True, text=True,
+                             env=dict(env, MTGPU_STAGING=staging)).stdout
+        _check_job(json.loads(out), pooled, want_seg, want_res)
+    # a failing submit inside one worker: the process must fail loudly
+    bad = subprocess.run([exe, path, "--threads", "2"], capture_output=True, text=True,
+                         env=dict(env, MTGPU_INJECT_SUBMIT_FAIL="1"))
+    assert bad.returncode != 0 and "injected" in bad.stderr and bad.stdout.strip() == ""

@@ -13,29 +13,8 @@ from mvtrim_amd import synth
 import oracle_binding as ob
 from np_model import check_frame_np
 
-GOLD = os.path.join(os.path.dirname(__file__), "golden")
-
-
-def build_mvs(case):
-    rows = [list(r) for r in case.get("mvs", [])]
-    for cx, cy, dx, dy, n in case.get("hits", []):
-        x, y = 16 * cx + 8, 16 * cy + 8
-        rows += [[x - dx, y - dy, x, y]] * n
-    mv = np.zeros(len(rows), dtype=m.MV_DTYPE)
-    if rows:
-        a = np.array(rows, dtype=np.int64)
-        mv["src_x"], mv["src_y"], mv["dst_x"], mv["dst_y"] = a[:, 0], a[:, 1], a[:, 2], a[:, 3]
-    return mv
-
-
-def load_hand_cases():
-    g = json.load(open(os.path.join(GOLD, "check_frame_hand_cases.json")))
-    out = []
-    for c in g["cases"]:
-        kw = dict(g["base"])
-        kw.update(c.get("over", {}))
-        out.append((c["name"], kw, c))
-    return g, out
+from golden_cases import (GOLD, build_mvs, filter_case_ticks, load_filter_cases, load_hand_cases,
+                          load_merge_cases, load_survey_segments, merge_case_ts)
 
 
 def test_hand_case_params():
@@ -101,6 +80,20 @@ def test_oracle_vs_numpy_model_random(seed):
                 assert flags[f] == flag          # early exit == full count vs max(1, clusters_needed)
 
 
+def test_oracle_rejects_negative_margin():
+    """vertical_margin < 0 would index before the grid in the reference (:237, :285): the oracle
+    refuses it, like the product's validate_params."""
+    import ctypes as C
+    p = ob.params_from_config(160, 160)
+    c = p.to_c()
+    c.vertical_margin = -1
+    grid = np.zeros(100, dtype=np.uint8)
+    mv = np.zeros(1, dtype=m.MV_DTYPE)
+    assert ob.lib().mto_check_frame(C.byref(c), mv.ctypes.data_as(C.c_void_p), 1, 1, grid.ctypes.data_as(C.c_void_p)) < 0
+    with pytest.raises(ValueError):
+        ob.scan_frames(m.ScanParams.from_c(c), mv, np.array([0, 1], dtype=np.uint64))
+
+
 def test_scan_frames_threads_and_null_has_sd():
     spec = synth.spec_1080p(seed=4, sub=1)
     spec.events = synth.scripted_events(spec, 40)
@@ -115,17 +108,9 @@ def test_scan_frames_threads_and_null_has_sd():
 
 # ------------------------------------------------------------------ merge
 
-def load_merge_cases():
-    g = json.load(open(os.path.join(GOLD, "merge_hand_cases.json")))
-    return [(c["name"], dict(g["base"], **c.get("over", {})), c) for c in g["cases"]]
-
-
 @pytest.mark.parametrize("name,kw,case", load_merge_cases(), ids=lambda x: x if isinstance(x, str) else None)
 def test_merge_hand_cases(name, kw, case):
-    ts = case.get("ts")
-    if ts is None:
-        a, b, s = case["ts_range"]
-        ts = list(np.arange(a, b, s, dtype=np.float64))
+    ts = merge_case_ts(case)
     mp = m.MergeParams(**kw)
     seg, res = ob.pool_and_merge(ts, mp, False)
     assert [list(x) for x in seg.tolist()] == case["segments"]
@@ -139,12 +124,7 @@ def test_merge_hand_cases(name, kw, case):
 
 
 def test_merge_reproduces_reference_run_recorded_in_survey():
-    g = json.load(open(os.path.join(GOLD, "survey_segments.json")))
-    ts = []
-    for a, b in g["motion_frame_runs"]:
-        ts += [float(3000 * i) * (1.0 / g["tb_den"]) for i in range(a, b + 1)]
-    mp = m.MergeParams(duration=g["duration"], max_gap_sec=g["max_gap_sec"], padding_sec=g["padding_sec"],
-                       min_savings_pct=5.0)
+    g, ts, mp = load_survey_segments()
     seg, res = ob.pool_and_merge(ts[::-1], mp, True)
     assert res["do_cut"] == 1
     got = [["%.17g" % s, "%.17g" % e] for s, e in seg.tolist()]
@@ -210,6 +190,39 @@ def test_frame_filter_and_chunks():
     assert ob.chunks(70.0, 30.0) == [(0.0, 30.0, 0), (30.0, 60.0, 1), (60.0, 70.0, 2)]
     assert ob.chunks(60.0, 30.0) == [(0.0, 30.0, 0), (30.0, 60.0, 1)]
     assert ob.chunks(0.0, 30.0) == []
+
+
+def test_frame_filter_hand_cases():
+    """tests/golden/frame_filter_hand_cases.json (hand-derived from src/motion_scanner.cpp:307-314,
+    357-371 and src/pipeline.cpp:163-167): the oracle AND the Python host mirror reproduce them."""
+    g = load_filter_cases()
+    tb = 1.0 / g["time_base_den"]
+    for c in g["frame_skip"]:
+        assert ob.lib().mto_frame_skip(c["fps"], c["target"]) == c["skip"], c
+        assert m.frame_skip(c["fps"], c["target"]) == c["skip"], c
+    for c in g["filter"]:
+        ticks = filter_case_ticks(g, c)
+        want_idx = [f - c["first"] for f in c["analysed"]]
+        want_pts = [f / 32.0 for f in c["analysed"]]
+        assert ob.filter_frames(ticks, tb, c["start"], c["end"], c["skip"]) == (want_idx, want_pts), c["name"]
+        assert m.filter_frames(ticks, tb, c["start"], c["end"], c["skip"]) == (want_idx, want_pts), c["name"]
+    for c in g["chunks"]:
+        want = [(a, b, i) for i, (a, b) in enumerate(c["chunks"])]
+        assert ob.chunks(c["duration"], c["chunk"]) == want, c
+        assert m.make_chunks(c["duration"], c["chunk"]) == want, c
+    # the whole-video case: chunks -> backward seek to the last keyframe -> filter
+    pl = g["pipeline"]
+    ticks = [g["ticks_per_frame"] * i for i in range(pl["n_frames"])]
+    skip = m.frame_skip(pl["fps"], pl["target_fps"])
+    pooled = []
+    for k, (c0, c1, _) in enumerate(m.make_chunks(pl["duration"], pl["chunk_sec"])):
+        target = int(c0 / tb)                                        # motion_scanner.cpp:322
+        first = max(f for f in pl["keyframes"] if ticks[f] <= target) if c0 > 0 else 0
+        for fn in (ob.filter_frames, m.filter_frames):
+            idx, pts = fn(ticks[first:], tb, c0, c1, skip)
+            assert [first + i for i in idx] == pl["per_chunk"][k], (k, fn)
+        pooled += [first + i for i in idx if (first + i) not in pl["keyframes"]]
+    assert pooled == pl["timestamps_frames"]
 
 
 # ------------------------------------------------------------------ property-based cross-check
