@@ -23,6 +23,15 @@ VARIANTS_FINE = [("default", dict()), ("chunk64", dict(MTGPU_FORCE_CHUNK="64")),
 VARIANTS_KERNEL = [("v%d" % v, dict(MTGPU_VARIANT=str(v))) for v in (0, 1, 2, 4, 8, 9, 10, 12, 3, 11, 6, 14)]
 VARIANTS_SLICES = [("auto", dict()), ("s1", dict(MTGPU_FORCE_SLICES="1")), ("s2", dict(MTGPU_FORCE_SLICES="2")),
                    ("s4", dict(MTGPU_FORCE_SLICES="4")), ("s8", dict(MTGPU_FORCE_SLICES="8"))]
+# row bands walked by one workgroup (spill queue): tile size / workgroup size (use with AB_VEC=4 on 4k_fine)
+VARIANTS_BANDS = [("auto", dict()), ("tile160", dict(MTGPU_BAND_LDS_KB="160")), ("tile80/b512", dict(MTGPU_FORCE_BLOCK="512")),
+                  ("tile53", dict(MTGPU_BAND_LDS_KB="53")), ("tile53/b512", dict(MTGPU_BAND_LDS_KB="53", MTGPU_FORCE_BLOCK="512")),
+                  ("tile40/b512", dict(MTGPU_BAND_LDS_KB="40", MTGPU_FORCE_BLOCK="512")),
+                  ("tile120", dict(MTGPU_BAND_LDS_KB="120"))]
+# one 160 KB tile vs two spill bands of <= 80 KB (use with AB_VEC=2 on 4k_fine)
+VARIANTS_TILE = [("single", dict()), ("bands80", dict(MTGPU_MAX_TILE_KB="80")),
+                 ("bands80/b512", dict(MTGPU_MAX_TILE_KB="80", MTGPU_FORCE_BLOCK="512")),
+                 ("bands53", dict(MTGPU_MAX_TILE_KB="53", MTGPU_BAND_LDS_KB="53"))]
 VARIANTS = [("fb32", dict(MTGPU_FORCE_FB="32")), ("fb2", dict(MTGPU_FORCE_FB="2")),
             ("fb32/b512", dict(MTGPU_FORCE_FB="32", MTGPU_FORCE_BLOCK="512")),
             ("fb2/b512", dict(MTGPU_FORCE_FB="2", MTGPU_FORCE_BLOCK="512")),
@@ -57,9 +66,11 @@ def main():
         d_off = torch.from_numpy(off_big).to(dev)
         alg = 40 * int(off_big[-1]) + 9 * frames
         scanners = []
-        vset = {"fine": VARIANTS_FINE, "kernel": VARIANTS_KERNEL, "slices": VARIANTS_SLICES}.get(os.environ.get("AB_SET"), VARIANTS)
+        vset = {"fine": VARIANTS_FINE, "kernel": VARIANTS_KERNEL, "slices": VARIANTS_SLICES,
+                "bands": VARIANTS_BANDS, "tile": VARIANTS_TILE}.get(os.environ.get("AB_SET"), VARIANTS)
         for name, env in vset:
-            for k in ("MTGPU_FORCE_FB", "MTGPU_FORCE_BLOCK", "MTGPU_FORCE_CHUNK", "MTGPU_VARIANT", "MTGPU_FORCE_SLICES"):
+            for k in ("MTGPU_FORCE_FB", "MTGPU_FORCE_BLOCK", "MTGPU_FORCE_CHUNK", "MTGPU_VARIANT", "MTGPU_FORCE_SLICES",
+                      "MTGPU_BAND_LDS_KB", "MTGPU_MAX_TILE_KB"):
                 os.environ.pop(k, None)
             os.environ.update(env)
             try:

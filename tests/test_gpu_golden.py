@@ -230,7 +230,13 @@ def test_config4_64_streams_scan_merge_gather(gpu_scanner_factory):
     streams = _gen_streams(S, F, seed0=4000)
     p = ob.params_from_config(1920, 1080)
     s = gpu_scanner_factory(m.ScanParams.from_config(1920, 1080))
-    mv = np.concatenate([st[1][0] for st in streams])
+    # (np.concatenate would repack the padded 40-byte record dtype into 32 bytes: fill a typed array)
+    mv = np.zeros(sum(len(st[1][0]) for st in streams), dtype=m.MV_DTYPE)
+    pos = 0
+    for st in streams:
+        mv[pos:pos + len(st[1][0])] = st[1][0]
+        pos += len(st[1][0])
+    assert mv.dtype.itemsize == 40
     counts = np.concatenate([np.diff(st[1][1].astype(np.int64)) for st in streams])
     off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
     pts = np.concatenate([st[1][2] for st in streams])
@@ -248,7 +254,9 @@ def test_config4_64_streams_scan_merge_gather(gpu_scanner_factory):
     flags = s.check_frames_device(d_mv, d_off, d_sd)
     seg, res = s.merge_streams_device(flags, d_pts, soff, d_mp, job_semantics=True, seg_cap=CAP)
     torch.cuda.synchronize()
-    assert np.array_equal(flags.cpu().numpy(), want_flags)
+    got_flags = flags.cpu().numpy()
+    bad = np.flatnonzero(got_flags != want_flags)
+    assert bad.size == 0, (bad.size, bad[:16], got_flags[bad[:16]], want_flags[bad[:16]], int(got_flags.sum()), int(want_flags.sum()))
     packed = mdist.pack_segment_lists(seg, res)
 
     lib = m.load_library()
@@ -311,7 +319,7 @@ def test_timerange_split_world_simulated(gpu_scanner_factory, world):
     import torch
     spec = synth.spec_1080p(seed=77, sub=2)
     n = 240
-    spec.events = synth.scripted_events(spec, n) + [synth.Event(100, 130, 50, 30, 4, 4, 9, 1)]
+    spec.events = synth.scripted_events(spec, n)
     mv, off, pts, sd = synth.gen_stream(spec, n)
     p = ob.params_from_config(1920, 1080)
     s = gpu_scanner_factory(m.ScanParams.from_config(1920, 1080))
