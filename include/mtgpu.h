@@ -143,6 +143,19 @@ int mtgpu_merge_segments(mtgpu_ctx *ctx, const double *ts, uint64_t n,
                          mt_segment *out, uint64_t cap, mt_merge_result *res);
 
 /*
+ * The same merge for ONE stream's pooled motion timestamps that already sit on the device (any
+ * order, duplicates allowed) — e.g. the timestamps all-gathered from the ranks that scanned
+ * time ranges of one video.  d_ts / d_seg / d_res are device pointers, `mp` is a host pointer
+ * (copied at call time).  Lists of a few thousand entries and more are sorted and merged by many
+ * workgroups (device-wide merge sort + scan), so a day of footage (~10^6 timestamps) merges in
+ * well under a millisecond.  Asynchronous on `stream`; d_res->status reports NaN input.
+ */
+int mtgpu_merge_timestamps_device(mtgpu_ctx *ctx, const double *d_ts, uint64_t n,
+                                  const mt_merge_params *mp, int job_semantics,
+                                  mt_segment *d_seg, uint64_t seg_cap, mt_merge_result *d_res,
+                                  void *stream);
+
+/*
  * Streams on the device, end to end: for S independent streams whose frames sit
  * contiguously in one batch (stream s owns frames [stream_off[s], stream_off[s+1])),
  * turn per-frame flags + per-frame pts into per-stream segment lists without

@@ -84,6 +84,8 @@ ABI = {
                                     C.c_uint32, C.c_void_p]),
     "mtgpu_merge_segments": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(MergeParamsC),
                                        C.c_int, C.c_void_p, C.c_uint64, C.POINTER(MergeResultC)]),
+    "mtgpu_merge_timestamps_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(MergeParamsC),
+                                                C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
     "mtgpu_merge_streams_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_uint32, C.c_void_p, C.c_int, C.c_void_p,
                                              C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),

@@ -25,4 +25,12 @@ struct MergeLaunch {
 
 hipError_t launch_merge(const MergeLaunch &L);
 
+// Multi-workgroup merge of ONE stream's pooled timestamps (any order, duplicates allowed), n >= 1:
+// device-wide sort (LDS tile sort + merge-path passes), then unique / gap merge / clamp / savings
+// with the same arithmetic as merge_streams_kernel.  ws: merge_large_ws_bytes(n) bytes.
+size_t merge_large_ws_bytes(unsigned long long n);
+hipError_t launch_merge_large(const double *d_ts, unsigned long long n, const mt_merge_params *d_mp, int job_semantics,
+                              void *ws, mt_segment *d_seg, unsigned long long seg_cap, mt_merge_result *d_res,
+                              hipStream_t st);
+
 }  // namespace mtgpu

@@ -247,6 +247,272 @@ __global__ __launch_bounds__(MB) void merge_streams_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Large single stream (mtgpu_merge_segments / mtgpu_merge_timestamps_device with n above
+// MERGE_LARGE_MIN): the same a8 + a9 arithmetic spread over many workgroups, for pooled
+// timestamp lists of 10^5 .. 10^7 entries (a day of footage analysed at 10 fps is ~10^6).
+//   sort    ml_tile_sort (bitonic in LDS, 2048-element tiles) + log2(n / 2048) ml_merge_pass
+//           launches (merge path: every thread finds its diagonal by binary search and merges
+//           4 outputs)                                                    (pipeline.cpp:302)
+//   unique  never materialised: on the sorted list, element i survives std::unique iff
+//           ts[i] != ts[i-1]; its predecessor ts[i-1] is then the previous DISTINCT value, so
+//           segment starts / ends are decided from neighbours in place          (:303-304)
+//   merge   ml_mark (per-tile counts of survivors and segment starts) -> ml_scan (one
+//           workgroup, exclusive scan of the tile counts) -> ml_emit (the element that starts
+//           segment k writes its raw start, the element that ends it its raw end) ->
+//           ml_finalize (padding, clamp, per-segment duration)            (:328-344, 351-353)
+//   sum     ml_result: ONE lane adds the durations in segment order (bit-exact with the
+//           sequential reference, :353), then savings / cut decision      (:355-358, 387-388)
+// All double arithmetic is the same plain IEEE add / sub / compare as in merge_streams_kernel.
+
+namespace {
+
+constexpr int LT = 2048;   // sort tile (elements)
+constexpr int LB = 512;    // threads of the sort / merge kernels
+constexpr int LV = LT / LB;
+
+struct LargeCtl {           // device-side control block of one large merge
+  unsigned int status;      // bit0: a NaN timestamp was seen
+  unsigned int pad;
+  unsigned long long n_unique;   // M
+  unsigned long long n_seg;      // K
+};
+
+__global__ __launch_bounds__(LB) void ml_tile_sort(const double *__restrict__ in, double *__restrict__ out,
+                                                    unsigned long long n, LargeCtl *ctl) {
+  __shared__ double s[LT];
+  const int tid = threadIdx.x;
+  const unsigned long long base = (unsigned long long)blockIdx.x * LT;
+  bool nan = false;
+  for (int i = tid; i < LT; i += LB) {
+    const unsigned long long g = base + i;
+    const double v = g < n ? in[g] : __builtin_inf();     // padding sorts to the end
+    nan |= (v != v);
+    s[i] = v;
+  }
+  if (nan) atomicOr(&ctl->status, 1u);
+  __syncthreads();
+  for (int k = 2; k <= LT; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = tid; t < LT / 2; t += LB) {
+        const int i = 2 * t - (t & (j - 1));              // index with a 0 bit at position log2(j)
+        const int p = i + j;
+        const bool up = (i & k) == 0;
+        const double a = s[i], b = s[p];
+        if (up ? (b < a) : (a < b)) { s[i] = b; s[p] = a; }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = tid; i < LT; i += LB) {
+    const unsigned long long g = base + i;
+    if (g < n) out[g] = s[i];
+  }
+}
+
+// One pass: runs of `run` sorted elements (run is a multiple of LT) are merged pairwise.
+__global__ __launch_bounds__(LB) void ml_merge_pass(const double *__restrict__ src, double *__restrict__ dst,
+                                                     unsigned long long n, unsigned long long run) {
+  const unsigned long long out0 = (unsigned long long)blockIdx.x * LT;
+  const unsigned long long a0 = (out0 / (2ull * run)) * 2ull * run;
+  const unsigned long long a1 = min(n, a0 + run), b1 = min(n, a0 + 2ull * run);
+  const unsigned long long na = a1 - a0, nb = b1 - a1;
+  const double *A = src + a0, *B = src + a1;
+  const unsigned long long d0 = (out0 - a0) + (unsigned long long)threadIdx.x * LV;
+  if (d0 >= na + nb) return;
+  // merge path: i = how many of the first d0 outputs come from A (ties: A first)
+  unsigned long long lo = d0 > nb ? d0 - nb : 0ull, hi = min(d0, na);
+  while (lo < hi) {
+    const unsigned long long mid = (lo + hi) >> 1;
+    if (A[mid] <= B[d0 - 1ull - mid]) lo = mid + 1ull; else hi = mid;
+  }
+  unsigned long long i = lo, j = d0 - lo;
+  double *o = dst + a0 + d0;
+#pragma unroll
+  for (int v = 0; v < LV; ++v) {
+    if (d0 + (unsigned long long)v >= na + nb) break;
+    const bool take_a = (j >= nb) || (i < na && A[i] <= B[j]);
+    o[v] = take_a ? A[i++] : B[j++];
+  }
+}
+
+// survivors of std::unique and segment starts, decided from the sorted neighbours
+__device__ __forceinline__ void classify(const double *__restrict__ ts, unsigned long long n, unsigned long long i,
+                                         double gap, bool &keep, bool &start, bool &end) {
+  keep = start = end = false;
+  if (i >= n) return;
+  const double c = ts[i];
+  const double p = i > 0 ? ts[i - 1] : 0.0;
+  keep = (i == 0) || !(c == p);                                   // :303-304 (operator==)
+  start = keep && (i == 0 || (c - p > gap));                      // :332-333, last_act == previous distinct value
+  const bool last_of_run = (i + 1 == n) || !(ts[i + 1] == c);
+  end = last_of_run && (i + 1 == n || (ts[i + 1] - c > gap));
+}
+
+__global__ __launch_bounds__(MB) void ml_mark(const double *__restrict__ ts, unsigned long long n,
+                                               const mt_merge_params *__restrict__ mp,
+                                               unsigned int *__restrict__ tile_keep, unsigned int *__restrict__ tile_start) {
+  __shared__ Shared sh;
+  const unsigned long long i = (unsigned long long)blockIdx.x * MB + threadIdx.x;
+  bool keep, start, end;
+  classify(ts, n, i, mp->max_gap_sec, keep, start, end);
+  unsigned int nk, ns;
+  (void)block_excl(keep, sh, &nk);
+  (void)block_excl(start, sh, &ns);
+  if (threadIdx.x == 0) { tile_keep[blockIdx.x] = nk; tile_start[blockIdx.x] = ns; }
+}
+
+// exclusive scan of the per-tile counts (one workgroup), totals into ctl
+__global__ __launch_bounds__(MB) void ml_scan(unsigned int *tile_keep, unsigned int *tile_start, unsigned int n_tiles,
+                                               unsigned long long *start_base, LargeCtl *ctl) {
+  __shared__ unsigned long long wsum[MW];
+  __shared__ unsigned long long carry_s, carry_k;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) { carry_s = 0ull; carry_k = 0ull; }
+  __syncthreads();
+  for (unsigned int base = 0; base < n_tiles; base += MB) {
+    const unsigned int t = base + tid;
+    const unsigned long long vs = t < n_tiles ? tile_start[t] : 0u;
+    const unsigned long long vk = t < n_tiles ? tile_keep[t] : 0u;
+    // inclusive wave scan of vs
+    unsigned long long x = vs;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned long long y = __shfl_up(x, d);
+      if (lane >= d) x += y;
+    }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    unsigned long long wbase = 0ull, tot = 0ull;
+#pragma unroll
+    for (int w = 0; w < MW; ++w) { if (w < wave) wbase += wsum[w]; tot += wsum[w]; }
+    if (t < n_tiles) start_base[t] = carry_s + wbase + x - vs;
+    __syncthreads();
+    // total of vk over the chunk
+    unsigned long long k = vk;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) k += __shfl_xor(k, d);
+    if (lane == 0) wsum[wave] = k;
+    __syncthreads();
+    if (tid == 0) {
+      unsigned long long kk = 0ull;
+      for (int w = 0; w < MW; ++w) kk += wsum[w];
+      carry_k += kk;
+      carry_s += tot;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) { ctl->n_unique = carry_k; ctl->n_seg = carry_s; }
+}
+
+__global__ __launch_bounds__(MB) void ml_emit(const double *__restrict__ ts, unsigned long long n,
+                                               const mt_merge_params *__restrict__ mp,
+                                               const unsigned long long *__restrict__ start_base,
+                                               double *__restrict__ raw_start, double *__restrict__ raw_end) {
+  __shared__ Shared sh;
+  const unsigned long long i = (unsigned long long)blockIdx.x * MB + threadIdx.x;
+  bool keep, start, end;
+  classify(ts, n, i, mp->max_gap_sec, keep, start, end);
+  unsigned int tot;
+  const unsigned int ex = block_excl(start, sh, &tot);
+  const unsigned long long kb = start_base[blockIdx.x] + ex;        // segments started before element i
+  if (start) raw_start[kb] = ts[i];
+  if (end) raw_end[kb + (start ? 1ull : 0ull) - 1ull] = ts[i];      // the segment whose start is the latest one <= i
+}
+
+__global__ __launch_bounds__(256) void ml_finalize(const mt_merge_params *__restrict__ mp, const LargeCtl *ctl,
+                                                    const double *__restrict__ raw_start, double *raw_end_durs,
+                                                    mt_segment *seg, unsigned long long seg_cap) {
+  const unsigned long long k = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+  if (k >= ctl->n_seg) return;
+  const double pad = mp->padding_sec, dur = mp->duration;
+  double st = std_max(0.0, raw_start[k] - pad);   // :337 / :343
+  double en = raw_end_durs[k] + pad;              // :338 / :344
+  en = std_min(en, dur);                          // :351
+  st = std_min(st, en);                           // :352
+  if (k < seg_cap) { seg[k].start = st; seg[k].end = en; }
+  raw_end_durs[k] = en - st;                      // :353 summand (in place of the raw end)
+}
+
+__global__ __launch_bounds__(MB) void ml_result(const mt_merge_params *__restrict__ mp, const LargeCtl *ctl,
+                                                 const double *__restrict__ durs, int job_semantics,
+                                                 mt_segment *seg, unsigned long long seg_cap, mt_merge_result *res) {
+  __shared__ double stage[MB];
+  const int tid = threadIdx.x;
+  if (ctl->status & 1u) {                          // NaN timestamp: outside the defined domain
+    if (tid == 0) {
+      res->n_timestamps = 0; res->n_segments = 0; res->time_removed = 0.0; res->saved_pct = 0.0;
+      res->do_cut = -1; res->status = MT_ERR_INVALID;
+    }
+    return;
+  }
+  const unsigned long long K = ctl->n_seg;
+  double out_dur = 0.0;
+  for (unsigned long long base = 0; base < K; base += MB) {       // :349-354, one lane adds in segment order
+    __syncthreads();
+    if (base + tid < K) stage[tid] = durs[base + tid];
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned int m = (unsigned int)((K - base < MB) ? (K - base) : MB);
+      for (unsigned int q = 0; q < m; ++q) out_dur += stage[q];
+    }
+  }
+  if (tid == 0) {
+    const double dur = mp->duration;
+    const double removed = dur - out_dur;
+    const double pct = (dur > 0) ? removed / dur * 100.0 : 0.0;
+    const int cut = (pct > mp->min_savings_pct) ? 1 : 0;
+    unsigned long long nseg = K;
+    if (job_semantics && !cut) {
+      if (seg_cap >= 1) { seg[0].start = 0.0; seg[0].end = dur; }
+      nseg = 1;
+    }
+    res->n_timestamps = ctl->n_unique; res->n_segments = nseg; res->time_removed = removed;
+    res->saved_pct = pct; res->do_cut = cut; res->status = MT_OK;
+  }
+}
+
+}  // namespace
+
+size_t merge_large_ws_bytes(unsigned long long n) {
+  const unsigned long long tiles = (n + MB - 1) / MB;
+  return sizeof(double) * 3ull * n + sizeof(unsigned int) * 2ull * tiles + sizeof(unsigned long long) * tiles + 64ull + 64ull;
+}
+
+// n >= 1.  ws: merge_large_ws_bytes(n) bytes, 16-byte aligned.  d_mp: ONE mt_merge_params on the device.
+hipError_t launch_merge_large(const double *d_ts, unsigned long long n, const mt_merge_params *d_mp, int job_semantics,
+                              void *ws, mt_segment *d_seg, unsigned long long seg_cap, mt_merge_result *d_res,
+                              hipStream_t st) {
+  if (n == 0 || n > (1ull << 40)) return hipErrorInvalidValue;
+  unsigned char *w = static_cast<unsigned char *>(ws);
+  LargeCtl *ctl = reinterpret_cast<LargeCtl *>(w);                      w += 64;
+  double *A = reinterpret_cast<double *>(w);                           w += sizeof(double) * n;
+  double *B = reinterpret_cast<double *>(w);                           w += sizeof(double) * n;
+  double *C = reinterpret_cast<double *>(w);                           w += sizeof(double) * n;
+  const unsigned long long tiles = (n + MB - 1) / MB;
+  unsigned long long *start_base = reinterpret_cast<unsigned long long *>(w);   w += sizeof(unsigned long long) * tiles;
+  unsigned int *tile_keep = reinterpret_cast<unsigned int *>(w);       w += sizeof(unsigned int) * tiles;
+  unsigned int *tile_start = reinterpret_cast<unsigned int *>(w);
+  hipError_t e = hipMemsetAsync(ctl, 0, 64, st);
+  if (e != hipSuccess) return e;
+  const unsigned long long sort_tiles = (n + LT - 1) / LT;
+  if (sort_tiles > 0x7fffffffull || tiles > 0x7fffffffull) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(ml_tile_sort, dim3((unsigned int)sort_tiles), dim3(LB), 0, st, d_ts, A, n, ctl);
+  double *src = A, *dst = B;
+  for (unsigned long long run = LT; run < n; run <<= 1) {
+    hipLaunchKernelGGL(ml_merge_pass, dim3((unsigned int)sort_tiles), dim3(LB), 0, st, src, dst, n, run);
+    double *t = src; src = dst; dst = t;
+  }
+  // src = sorted list; dst (the other ping-pong buffer) and C are free: raw starts / raw ends + durations
+  hipLaunchKernelGGL(ml_mark, dim3((unsigned int)tiles), dim3(MB), 0, st, src, n, d_mp, tile_keep, tile_start);
+  hipLaunchKernelGGL(ml_scan, dim3(1), dim3(MB), 0, st, tile_keep, tile_start, (unsigned int)tiles, start_base, ctl);
+  hipLaunchKernelGGL(ml_emit, dim3((unsigned int)tiles), dim3(MB), 0, st, src, n, d_mp, start_base, dst, C);
+  const unsigned long long fin_blocks = (n + 255) / 256;               // K <= n (K itself lives on the device)
+  hipLaunchKernelGGL(ml_finalize, dim3((unsigned int)fin_blocks), dim3(256), 0, st, d_mp, ctl, dst, C, d_seg, seg_cap);
+  hipLaunchKernelGGL(ml_result, dim3(1), dim3(MB), 0, st, d_mp, ctl, C, job_semantics, d_seg, seg_cap, d_res);
+  return hipGetLastError();
+}
+
 hipError_t launch_merge(const MergeLaunch &L) {
   if (L.n_streams == 0) return hipSuccess;
   hipLaunchKernelGGL(merge_streams_kernel, dim3(L.n_streams), dim3(MB), 0, L.stream, L.flags,

@@ -78,6 +78,7 @@ struct mtgpu_ctx {
   int wide_chunk_rows = 0, wide_lds_bytes = 0;   // single-workgroup-per-CU layout (see make_plan)
   int item_chunk = 0;    // MTGPU_ITEM_CHUNK (tests): work items per kernel launch, 0 = 2^30
   int lds_max = 0;       // device limit of LDS per workgroup
+  uint64_t merge_large_min = 4096;   // timestamp lists at least this long take the multi-workgroup merge (MTGPU_MERGE_LARGE_MIN)
   std::mutex mu;         // guards the staging buffers below
   DevBuf d_mv, d_off, d_sd, d_flags, d_misc;
 };
@@ -234,6 +235,10 @@ int make_plan(mtgpu_ctx *c, int lds_max, int cu_count) {
   k.slices = 1;
   c->item_chunk = env_int("MTGPU_ITEM_CHUNK", 0);
   if (c->item_chunk < 0) c->item_chunk = 0;
+  {
+    const int lm = env_int("MTGPU_MERGE_LARGE_MIN", 0);
+    if (lm > 0) c->merge_large_min = (uint64_t)lm;
+  }
   c->plan.counter_mode = mode;
   c->plan._pad = 0;
   return MT_OK;
@@ -532,6 +537,74 @@ int mtgpu_merge_streams_device(mtgpu_ctx *c, const uint8_t *d_flags, const doubl
   return MT_OK;
 }
 
+}  // extern "C" (continued below)
+
+namespace {
+
+// One stream's pooled timestamps, device-resident: small lists go to the one-workgroup stream
+// kernel, large ones (>= merge_large_min) to the multi-workgroup path.  `ws` must hold
+// merge_ts_ws_bytes(n); d_mp is ONE parameter block on the device.  Asynchronous on st.
+size_t merge_ts_ws_bytes(const mtgpu_ctx *c, uint64_t n) {
+  if (n >= c->merge_large_min && n > 0) return mtgpu::merge_large_ws_bytes(n);
+  return sizeof(double) * 2 * (size_t)n + 64;          // [off[2] | pad] [ws 2n]
+}
+
+int merge_ts_on(mtgpu_ctx *c, const double *d_ts, uint64_t n, const mt_merge_params *d_mp, int job_semantics,
+                void *ws, mt_segment *d_seg, uint64_t seg_cap, mt_merge_result *d_res, hipStream_t st) {
+  if (n >= c->merge_large_min && n > 0) {
+    hipError_t e = mtgpu::launch_merge_large(d_ts, n, d_mp, job_semantics, ws, d_seg, seg_cap, d_res, st);
+    if (e != hipSuccess) return hip_fail(e, "large merge launch");
+    return MT_OK;
+  }
+  unsigned char *w = static_cast<unsigned char *>(ws);
+  const uint64_t off[2] = {0, n};
+  HIP_TRY(hipMemcpyAsync(w, off, sizeof off, hipMemcpyHostToDevice, st));
+  mtgpu::MergeLaunch L;
+  L.flags = nullptr;
+  L.pts = d_ts;
+  L.stream_off = reinterpret_cast<const unsigned long long *>(w);
+  L.n_frames_total = n;
+  L.mp = d_mp;
+  L.job_semantics = job_semantics;
+  L.ts_ws = reinterpret_cast<double *>(w + 64);
+  L.seg = d_seg;
+  L.seg_cap = seg_cap;
+  L.res = d_res;
+  L.n_streams = 1;
+  L.stream = st;
+  hipError_t e = mtgpu::launch_merge(L);
+  if (e != hipSuccess) return hip_fail(e, "merge launch");
+  return MT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mtgpu_merge_timestamps_device(mtgpu_ctx *c, const double *d_ts, uint64_t n, const mt_merge_params *mp,
+                                  int job_semantics, mt_segment *d_seg, uint64_t seg_cap,
+                                  mt_merge_result *d_res, void *stream) {
+  if (!c) return fail(MT_ERR_INVALID, "ctx is NULL");
+  if (!mp || !d_res) return fail(MT_ERR_INVALID, "mp/res is NULL");
+  if (n > 0 && !d_ts) return fail(MT_ERR_INVALID, "ts is NULL with n > 0");
+  if (seg_cap > 0 && !d_seg) return fail(MT_ERR_INVALID, "seg is NULL with seg_cap > 0");
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const size_t wsb = merge_ts_ws_bytes(c, n) + 64;               // + the parameter block
+  void *scratch = nullptr;
+  HIP_TRY(hipMallocAsync(&scratch, wsb, st));
+  unsigned char *w = static_cast<unsigned char *>(scratch);
+  int rc = MT_OK;
+  hipError_t e = hipMemcpyAsync(w, mp, sizeof *mp, hipMemcpyHostToDevice, st);   // pageable source: staged at call time
+  if (e != hipSuccess) rc = hip_fail(e, "H2D merge params");
+  if (rc == MT_OK)
+    rc = merge_ts_on(c, d_ts, n, reinterpret_cast<const mt_merge_params *>(w), job_semantics, w + 64, d_seg, seg_cap,
+                     d_res, st);
+  hipError_t e2 = hipFreeAsync(scratch, st);
+  if (rc == MT_OK && e2 != hipSuccess) rc = hip_fail(e2, "hipFreeAsync");
+  return rc;
+}
+
 int mtgpu_merge_segments(mtgpu_ctx *c, const double *ts, uint64_t n, const mt_merge_params *mp,
                          int job_semantics, mt_segment *out, uint64_t cap, mt_merge_result *res) {
   if (!c) return fail(MT_ERR_INVALID, "ctx is NULL");
@@ -541,39 +614,24 @@ int mtgpu_merge_segments(mtgpu_ctx *c, const double *ts, uint64_t n, const mt_me
 
   std::lock_guard<std::mutex> lock(c->mu);
   HIP_TRY(hipSetDevice(c->device));
-  // one staging block: pts[n] | ws[2n] | seg[segs] | off[2] | mp | res
+  // one staging block: mp | res | pts[n] | seg[segs] | workspace
   const uint64_t segs = (cap < n ? cap : n) + 1;        // K <= n; +1 for the full-copy segment
-  size_t o_pts = 0;
-  size_t o_ws = o_pts + sizeof(double) * (size_t)n;
-  size_t o_seg = o_ws + sizeof(double) * 2 * (size_t)n;
-  size_t o_off = o_seg + sizeof(mt_segment) * (size_t)segs;
-  size_t o_mp = o_off + sizeof(uint64_t) * 2;
-  size_t o_res = o_mp + sizeof(mt_merge_params);
-  size_t total = o_res + sizeof(mt_merge_result);
+  size_t o_mp = 0;
+  size_t o_res = o_mp + 64;
+  size_t o_pts = o_res + 64;
+  size_t o_seg = o_pts + sizeof(double) * (size_t)n;
+  size_t o_ws = (o_seg + sizeof(mt_segment) * (size_t)segs + 63) & ~(size_t)63;
+  size_t total = o_ws + merge_ts_ws_bytes(c, n);
   int rc = c->d_misc.reserve(total);
   if (rc != MT_OK) return rc;
   unsigned char *d = static_cast<unsigned char *>(c->d_misc.p);
   hipStream_t st = c->stream;
-  const uint64_t off[2] = {0, n};
   if (n) HIP_TRY(hipMemcpyAsync(d + o_pts, ts, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(d + o_off, off, sizeof off, hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemcpyAsync(d + o_mp, mp, sizeof *mp, hipMemcpyHostToDevice, st));
-
-  mtgpu::MergeLaunch L;
-  L.flags = nullptr;
-  L.pts = reinterpret_cast<const double *>(d + o_pts);
-  L.stream_off = reinterpret_cast<const unsigned long long *>(d + o_off);
-  L.n_frames_total = n;
-  L.mp = reinterpret_cast<const mt_merge_params *>(d + o_mp);
-  L.job_semantics = job_semantics;
-  L.ts_ws = reinterpret_cast<double *>(d + o_ws);
-  L.seg = reinterpret_cast<mt_segment *>(d + o_seg);
-  L.seg_cap = segs;
-  L.res = reinterpret_cast<mt_merge_result *>(d + o_res);
-  L.n_streams = 1;
-  L.stream = st;
-  hipError_t e = mtgpu::launch_merge(L);
-  if (e != hipSuccess) return hip_fail(e, "merge launch");
+  rc = merge_ts_on(c, reinterpret_cast<const double *>(d + o_pts), n, reinterpret_cast<const mt_merge_params *>(d + o_mp),
+                   job_semantics, d + o_ws, reinterpret_cast<mt_segment *>(d + o_seg), segs,
+                   reinterpret_cast<mt_merge_result *>(d + o_res), st);
+  if (rc != MT_OK) return rc;
   HIP_TRY(hipMemcpyAsync(res, d + o_res, sizeof *res, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   if (res->status != MT_OK) return fail(res->status, "timestamps contain NaN");

@@ -133,14 +133,9 @@ def scan_and_merge_timerange(scanner, mv, frame_off, pts, merge_params, has_sd=N
     flags = scanner.check_frames_device(mv, frame_off, has_sd)
     local_ts = pts[flags.bool()]
     pooled = gather_timestamps(local_ts, group=group).contiguous()
-    n = pooled.numel()
     dev = pts.device
-    soff = torch.tensor([0, n], dtype=torch.int64, device=dev)
-    mp = torch.from_numpy(merge_params.to_record().view(np.uint8).copy()).to(dev)
-    if n == 0:
-        pooled = torch.zeros(1, dtype=torch.float64, device=dev)
-    seg, res = scanner.merge_streams_device(None, pooled, soff, mp, job_semantics, seg_cap)
+    seg, res = scanner.merge_timestamps_device(pooled, merge_params, job_semantics, seg_cap)
     torch.cuda.synchronize(dev)
     rec = results_from_bytes(res.cpu().numpy())[0]
     k = min(int(rec["n_segments"]), seg_cap)
-    return seg[0, :k].cpu().numpy(), rec
+    return seg[:k].cpu().numpy(), rec

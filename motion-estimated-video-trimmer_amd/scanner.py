@@ -295,6 +295,24 @@ class MotionScanner:
         out = {n: getattr(res, n) for n, _ in MergeResultC._fields_}
         return seg[:res.n_segments].copy(), out
 
+    def merge_timestamps_device(self, ts, mp: MergeParams, job_semantics: bool = False, seg_cap: int = 64,
+                                stream=None):
+        """The same merge for ONE stream's pooled timestamps already on the device (1-D float64
+        CUDA tensor, any order, duplicates allowed); large lists are sorted / merged by many
+        workgroups.  Returns (segments float64 [seg_cap, 2], result uint8 [40]) device tensors;
+        asynchronous on `stream` (default: torch's current stream)."""
+        import torch
+        assert ts.dtype == torch.float64 and ts.is_contiguous()
+        dev = ts.device
+        seg = torch.zeros((seg_cap, 2), dtype=torch.float64, device=dev)
+        res = torch.zeros(MERGE_RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+        st = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
+        c_mp = mp.to_c()
+        check(self._lib.mtgpu_merge_timestamps_device(
+            self._ctx, ts.data_ptr() if ts.numel() else None, ts.numel(), C.byref(c_mp),
+            1 if job_semantics else 0, seg.data_ptr(), seg_cap, res.data_ptr(), st))
+        return seg, res
+
     def merge_streams_device(self, flags, pts, stream_off, merge_params, job_semantics=False,
                              seg_cap=64, stream=None, out=None):
         """Per-stream timestamp pooling + merge without leaving the device.

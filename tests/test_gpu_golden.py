@@ -517,3 +517,88 @@ def test_cpp_host_pipeline_4k_fine_and_failure_exit_code(tmp_path):
     bad = subprocess.run([exe, path, "--threads", "2"], capture_output=True, text=True,
                          env=dict(env, MTGPU_INJECT_SUBMIT_FAIL="1"))
     assert bad.returncode != 0 and "injected" in bad.stderr and bad.stdout.strip() == ""
+
+
+# ------------------------------------------------------------------ large merges (multi-workgroup path)
+
+def _merge_inputs(rng, n, variant):
+    dur = 86400.0
+    base = np.sort(rng.rand(n) * dur)
+    ts = np.round(base / 60.0) * 60.0 + rng.rand(n) * 20.0       # clusters: gaps on both sides of MAX_GAP_SEC
+    if variant == "sorted":
+        return np.sort(ts)
+    if variant == "chunk_runs":                                  # pooled per-chunk results: sorted runs, any order
+        v = np.sort(ts)
+        runs = np.array_split(v, max(1, n // 700))
+        order = rng.permutation(len(runs))
+        return np.concatenate([runs[i] for i in order])
+    if variant == "dups":
+        return rng.permutation(np.concatenate([ts, ts[: n // 2 + 1], ts[:1]]))
+    return rng.permutation(ts)
+
+
+def _check_merge_equal(got_seg, got_res, want_seg, want_res):
+    assert got_res["n_timestamps"] == want_res["n_timestamps"]
+    assert got_res["n_segments"] == want_res["n_segments"] and got_res["do_cut"] == want_res["do_cut"]
+    assert bits([got_res["time_removed"], got_res["saved_pct"]]).tolist() == \
+        bits([want_res["time_removed"], want_res["saved_pct"]]).tolist()
+    assert np.array_equal(bits(got_seg["start"]), bits(want_seg["start"]))
+    assert np.array_equal(bits(got_seg["end"]), bits(want_seg["end"]))
+
+
+@pytest.mark.parametrize("job", [False, True])
+def test_merge_large_path_edge_sizes(gpu_scanner_factory, monkeypatch, job):
+    """The multi-workgroup merge (tile sort + merge-path passes + scan) forced on for every size
+    (MTGPU_MERGE_LARGE_MIN=1): tile / run boundaries, duplicates, all-equal, every gap a split."""
+    monkeypatch.setenv("MTGPU_MERGE_LARGE_MIN", "1")
+    s = gpu_scanner_factory(m.ScanParams.from_config(1920, 1080))
+    monkeypatch.delenv("MTGPU_MERGE_LARGE_MIN")
+    rng = np.random.RandomState(11)
+    mps = [m.MergeParams(duration=86400.0, max_gap_sec=5.0, padding_sec=0.5, min_savings_pct=5.0),
+           m.MergeParams(duration=40000.0, max_gap_sec=0.0, padding_sec=2.0, min_savings_pct=5.0),
+           m.MergeParams(duration=0.0, max_gap_sec=-1.0, padding_sec=0.0, min_savings_pct=5.0)]
+    for n in [1, 2, 3, 1023, 1024, 1025, 2047, 2048, 2049, 4095, 4096, 4097, 6143, 8192, 8193, 20000, 70000]:
+        for variant in ("sorted", "shuffled", "dups", "chunk_runs"):
+            v = _merge_inputs(rng, n, variant)
+            for mp in mps:
+                want = ob.pool_and_merge(v, mp, job)
+                got = s.merge_segments(v, mp, job)
+                _check_merge_equal(got[0], got[1], want[0], want[1])
+    same = np.full(5000, 7.25)
+    for mp in mps:
+        _check_merge_equal(*s.merge_segments(same, mp, job), *ob.pool_and_merge(same, mp, job))
+    with pytest.raises(m.MtgpuError) as ei:
+        s.merge_segments(np.r_[rng.rand(3000), float("nan"), rng.rand(3000)], mps[0], job)
+    assert ei.value.code == 1
+    with pytest.raises(m.MtgpuError) as ei:                      # capacity: need reported, like the small path
+        s.merge_segments(np.arange(6000.0) * 10.0, mps[0], False, cap=10)
+    assert ei.value.code == 2
+
+
+@pytest.mark.parametrize("n", [100_000, 1_000_000])
+def test_merge_large_inputs_bit_exact(gpu_scanner_factory, n):
+    """Pooled timestamp lists of 10^5 / 10^6 entries (a day of footage at ~10 fps): shuffled, with
+    duplicates, and as out-of-order sorted runs — bit-exact against the oracle, through the host
+    entry point and the device-resident one."""
+    import torch
+    s = gpu_scanner_factory(m.ScanParams.from_config(1920, 1080))
+    rng = np.random.RandomState(n % 1000 + 3)
+    mp = m.MergeParams(duration=86400.0, max_gap_sec=5.0, padding_sec=0.5, min_savings_pct=5.0)
+    for variant in ("shuffled", "dups", "chunk_runs"):
+        v = _merge_inputs(rng, n, variant)
+        want_seg, want_res = ob.pool_and_merge(v, mp, True)
+        assert want_res["n_segments"] > 100
+        got_seg, got_res = s.merge_segments(v, mp, True)
+        _check_merge_equal(got_seg, got_res, want_seg, want_res)
+        cap = int(want_res["n_segments"]) + 8
+        dseg, dres = s.merge_timestamps_device(torch.from_numpy(v).cuda(), mp, True, seg_cap=cap)
+        torch.cuda.synchronize()
+        rec = m.results_from_bytes(dres.cpu().numpy()[None, :])[0]
+        k = int(rec["n_segments"])
+        assert k == want_res["n_segments"] and int(rec["n_timestamps"]) == want_res["n_timestamps"]
+        assert dseg[:k].cpu().numpy().tobytes() == np.stack([want_seg["start"], want_seg["end"]], 1).tobytes()
+        assert bits([rec["time_removed"], rec["saved_pct"]]).tolist() == \
+            bits([want_res["time_removed"], want_res["saved_pct"]]).tolist()
+    # worst case for the in-order sum: every timestamp its own segment
+    v = rng.permutation(np.arange(n, dtype=np.float64) * 7.0)
+    _check_merge_equal(*s.merge_segments(v, mp, False), *ob.pool_and_merge(v, mp, False))
