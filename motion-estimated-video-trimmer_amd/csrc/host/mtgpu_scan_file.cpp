@@ -21,10 +21,11 @@ static bool g_print_ts = false;   // --timestamps: also print the pooled motion 
 static void print_job(const std::string &input, const PipelineResult &r, const std::vector<mt_segment> &segs) {
   std::printf("{\"input\": \"%s\", \"chunks\": %d, \"threads\": %d, \"motion_frames\": %zu, \"n_timestamps\": %llu, "
               "\"do_cut\": %d, \"time_removed\": %.17g, \"saved_pct\": %.17g, \"seek_us\": %ld, "
-              "\"decode_us\": %ld, \"analyze_us\": %ld, \"init_us\": %ld, \"scan_wall_us\": %ld, \"segments\": [",
+              "\"decode_us\": %ld, \"analyze_us\": %ld, \"init_us\": %ld, \"scan_wall_us\": %ld, \"scan_work_us\": %ld, "
+              "\"segments\": [",
               input.c_str(), r.chunks, r.threads, r.motion_frames, (unsigned long long)r.merge.n_timestamps,
               r.merge.do_cut, r.merge.time_removed, r.merge.saved_pct, r.seek_us, r.decode_us, r.analyze_us, r.init_us,
-              r.scan_wall_us);
+              r.scan_wall_us, r.scan_work_us);
   for (size_t i = 0; i < segs.size(); ++i)
     std::printf("%s[%.17g, %.17g]", i ? ", " : "", segs[i].start, segs[i].end);
   std::printf("]");

@@ -217,6 +217,8 @@ int make_plan(mtgpu_ctx *c, int lds_max, int cu_count) {
   // 4 workgroups/CU (measured +2.5 % over 256 on 1080p); tiles above 48 KB run 1-2
   // workgroups/CU and take 16 waves each.
   int block = lds <= 48u * 1024u ? 512 : 1024;
+  // row bands (two <= 80 KB tiles per CU): 8 waves per workgroup measured +4 % over 16 (scripts/ab_scan.py, AB_SET=bands)
+  if (k.bands > 1) block = 512;
   const int fblock = env_int("MTGPU_FORCE_BLOCK", 0);
   if (fblock == 256 || fblock == 512 || fblock == 1024) block = fblock;
   c->plan.block_threads = block;
