@@ -59,6 +59,13 @@ struct Config {   // same variables, defaults and parse types as config.hpp:56-1
   static double chunk_duration_sec() { return env_d("CHUNK_DURATION_SEC", 30.0); }
   static double target_fps() { return env_d("TARGET_FPS", 0.0); }
   static double min_savings_pct() { return env_d("MIN_SAVINGS_PCT", 5.0); }
+  // not in the reference: pinned staging per batch of the host dispatcher, in MiB
+  // (default: 4 for the compact layout — 16 workers x 3 batches stay inside the host's L3, so the DMA
+  //  engine reads staging from cache — and 16 for the 40-byte layout)
+  static int batch_mib() {
+    const int v = env_i("MTGPU_BATCH_MB", staging_layout() == MT_LAYOUT_AOS40 ? 16 : 4);
+    return v < 1 ? 1 : v;
+  }
   // not in the reference: staging layout of the host dispatcher (include/mtgpu.h), "aos40" or "compact8"
   static int staging_layout() {
     const char *v = std::getenv("MTGPU_STAGING");
@@ -241,6 +248,10 @@ class GpuMotionScanner {   // public shape of MotionScanner (motion_scanner.hpp:
   mtgpu_batch *cur_ = nullptr;
   int inflight_ = 0;
   std::string err_;
+  long copy_us_ = 0, submit_us_ = 0, wait_us_ = 0;   // inside analyze_us: copy-out / submit calls / waiting for the GPU
+  static long since(std::chrono::high_resolution_clock::time_point t0) {
+    return (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::high_resolution_clock::now() - t0).count();
+  }
 
   bool ok(int rc) { if (rc != MT_OK) { err_ = mtgpu_last_error(); return false; } return true; }
 
@@ -249,7 +260,10 @@ class GpuMotionScanner {   // public shape of MotionScanner (motion_scanner.hpp:
     const uint8_t *flags = nullptr;
     const double *pts = nullptr;
     uint32_t n = 0;
-    if (!ok(mtgpu_pipe_collect(pipe_, &b, &flags, &pts, nullptr, &n))) return false;
+    const auto w0 = std::chrono::high_resolution_clock::now();
+    const bool got = ok(mtgpu_pipe_collect(pipe_, &b, &flags, &pts, nullptr, &n));
+    wait_us_ += since(w0);
+    if (!got) return false;
     for (uint32_t i = 0; i < n; ++i)
       if (flags[i]) ts.push_back(pts[i]);                    // :382-383
     --inflight_;
@@ -257,7 +271,10 @@ class GpuMotionScanner {   // public shape of MotionScanner (motion_scanner.hpp:
   }
   bool submit() {
     if (!cur_) return true;
-    if (!ok(mtgpu_pipe_submit(pipe_, cur_))) return false;
+    const auto s0 = std::chrono::high_resolution_clock::now();
+    const bool sent = ok(mtgpu_pipe_submit(pipe_, cur_));
+    submit_us_ += since(s0);
+    if (!sent) return false;
     cur_ = nullptr;
     ++inflight_;
     return true;
@@ -269,7 +286,9 @@ class GpuMotionScanner {   // public shape of MotionScanner (motion_scanner.hpp:
         if (rc == MT_ERR_BUSY) { if (!collect_one(ts)) return false; continue; }   // back-pressure
         if (!ok(rc)) return false;
       }
+      const auto c0 = std::chrono::high_resolution_clock::now();
       int rc = mtgpu_batch_add_frame(cur_, f.mv, f.mv_bytes, f.has_side_data ? 1 : 0, pts, 0);
+      copy_us_ += since(c0);
       if (rc == MT_ERR_CAPACITY) { if (!submit()) return false; continue; }
       return ok(rc);
     }
@@ -291,15 +310,21 @@ class GpuMotionScanner {   // public shape of MotionScanner (motion_scanner.hpp:
   // after each scan_range — a range that failed returns only part of its timestamps.
   const std::string &error() const { return err_; }
   bool failed() const { return !err_.empty(); }
+  long copy_us() const { return copy_us_; }
+  long submit_us() const { return submit_us_; }
+  long wait_us() const { return wait_us_; }
   mtgpu_ctx *context() { return be_->ctx(); }
 
-  // batch_records == 0: sized from the source — room for a few frames of one 40-byte record
-  // per 4x4 block (the finest partition H.264/HEVC export); a single frame beyond a whole
-  // batch still works (the pipe grows an empty batch, include/mtgpu.h).
+  // batch_records == 0: sized from the source and the staging layout — MTGPU_BATCH_MB MiB of
+  // pinned staging per batch, and never less than two frames of one record per 4x4 block (the
+  // finest partition H.264/HEVC export).  Batches of a few MiB amortise the per-batch copy /
+  // launch / event calls; a single frame beyond a whole batch still works (the pipe grows an
+  // empty batch, include/mtgpu.h).
   bool initialize(uint64_t batch_records = 0, uint32_t batch_frames = 256, int n_buffers = 3) {
     if (batch_records == 0) {
       const uint64_t fine = (uint64_t)((src_.width() + 3) / 4) * (uint64_t)((src_.height() + 3) / 4);
-      batch_records = std::max<uint64_t>(1u << 17, 2 * fine);
+      const uint64_t rec_bytes = Config::staging_layout() == MT_LAYOUT_AOS40 ? MT_MV_BYTES : MT_COMPACT_BYTES;
+      batch_records = std::max<uint64_t>(2 * fine, ((uint64_t)Config::batch_mib() << 20) / rec_bytes);
     }
     if (!be_->ensure(src_.width(), src_.height(), device_, batch_records, batch_frames, n_buffers, err_)) return false;
     pipe_ = be_->pipe();
@@ -368,6 +393,8 @@ struct PipelineResult {
   long seek_us = 0, decode_us = 0, analyze_us = 0;   // summed over workers, as pipeline.cpp:229-233
   long init_us = 0, scan_wall_us = 0;                // worker init (summed) / wall time of the scan phase
   long scan_work_us = 0;                             // wall time from "every worker initialised" to the last result
+  long copy_us = 0, submit_us = 0, wait_us = 0;      // parts of analyze_us (summed over workers): copy-out into pinned
+                                                     // staging, submit calls, waiting for the GPU
   std::string error;
 };
 
@@ -391,7 +418,7 @@ int run_scan_pipeline(MakeSource make_source, int num_threads, PipelineResult &o
   int chunk_id = 0;
   for (double t = 0; t < duration; t += chunk)                           // :163-167
     tasks.push({t, std::min(t + chunk, duration), chunk_id++});
-  std::atomic<long> seek_us{0}, decode_us{0}, analyze_us{0}, init_us{0};
+  std::atomic<long> seek_us{0}, decode_us{0}, analyze_us{0}, init_us{0}, copy_us{0}, submit_us{0}, wait_us{0};
   const auto wall0 = std::chrono::high_resolution_clock::now();
   std::mutex err_mu;
   std::vector<std::thread> workers;
@@ -436,6 +463,7 @@ int run_scan_pipeline(MakeSource make_source, int num_threads, PipelineResult &o
         if (!r.empty()) results.add(std::move(r));
       }
       seek_us += s; decode_us += d; analyze_us += a;
+      copy_us += scanners[i]->copy_us(); submit_us += scanners[i]->submit_us(); wait_us += scanners[i]->wait_us();
     });
   }
   tasks.finish();
@@ -443,6 +471,7 @@ int run_scan_pipeline(MakeSource make_source, int num_threads, PipelineResult &o
   out.chunks = chunk_id;
   out.threads = num_threads;
   out.seek_us = seek_us; out.decode_us = decode_us; out.analyze_us = analyze_us; out.init_us = init_us;
+  out.copy_us = copy_us; out.submit_us = submit_us; out.wait_us = wait_us;
   {
     const auto wall1 = std::chrono::high_resolution_clock::now();
     out.scan_wall_us = (long)std::chrono::duration_cast<std::chrono::microseconds>(wall1 - wall0).count();

@@ -6,6 +6,7 @@
 // thread (here: printed).  Configuration comes from the same environment variables as the
 // reference (MV_THRESHOLD_SQ, VECTORS_NEEDED, CHUNK_DURATION_SEC, TARGET_FPS, ...).
 // Prints one JSON object per input with a job: the FFmpegJob segment list (%.17g) + merge result.
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -16,16 +17,56 @@
 
 using namespace mtgpu_host;
 
+// --repeat N (rate measurements only): the input presented as N back-to-back copies of itself — a
+// long video whose MV bytes stay cache-resident, like side data a decoder thread has just written,
+// instead of 10+ GB streamed from the page cache.
+class RepeatSource : public FrameSource {
+  const MtmvFile &f_;
+  uint64_t reps_, pos_ = 0;
+  int64_t period_;     // ticks per copy
+ public:
+  RepeatSource(const MtmvFile &f, uint64_t reps) : f_(f), reps_(reps) {
+    period_ = (int64_t)std::llround(f.hdr->duration * (double)f.hdr->tb_den / (double)f.hdr->tb_num);
+  }
+  int width() const override { return (int)f_.hdr->width; }
+  int height() const override { return (int)f_.hdr->height; }
+  double duration() const override { return f_.hdr->duration * (double)reps_; }
+  double fps() const override { return f_.hdr->fps; }
+  double time_base() const override { return (double)f_.hdr->tb_num / (double)f_.hdr->tb_den; }
+  void seek(double seconds) override {
+    const int64_t target = static_cast<int64_t>(seconds / time_base());
+    uint64_t rep = period_ > 0 ? (uint64_t)(target / period_) : 0;
+    if (rep >= reps_) rep = reps_ - 1;
+    const int64_t local = target - (int64_t)rep * period_;
+    uint64_t key = 0;
+    for (uint64_t i = 0; i < f_.hdr->n_frames && f_.frames[i].pts <= local; ++i)
+      if (f_.frames[i].key) key = i;
+    pos_ = rep * f_.hdr->n_frames + key;
+  }
+  bool next(Frame &fr) override {
+    const uint64_t n = f_.hdr->n_frames;
+    if (n == 0 || pos_ >= reps_ * n) return false;
+    const uint64_t rep = pos_ / n;
+    const MtmvFrameRec &r = f_.frames[pos_ % n];
+    ++pos_;
+    fr.pts = r.pts + (int64_t)rep * period_;
+    fr.has_side_data = r.has_sd != 0;
+    fr.mv = r.has_sd ? f_.records + 40ull * r.rec_off : nullptr;
+    fr.mv_bytes = r.has_sd ? 40ull * r.n_rec : 0;
+    return true;
+  }
+};
+
 static bool g_print_ts = false;   // --timestamps: also print the pooled motion timestamps, sorted (%.17g)
 
 static void print_job(const std::string &input, const PipelineResult &r, const std::vector<mt_segment> &segs) {
   std::printf("{\"input\": \"%s\", \"chunks\": %d, \"threads\": %d, \"motion_frames\": %zu, \"n_timestamps\": %llu, "
               "\"do_cut\": %d, \"time_removed\": %.17g, \"saved_pct\": %.17g, \"seek_us\": %ld, "
               "\"decode_us\": %ld, \"analyze_us\": %ld, \"init_us\": %ld, \"scan_wall_us\": %ld, \"scan_work_us\": %ld, "
-              "\"segments\": [",
+              "\"copy_us\": %ld, \"submit_us\": %ld, \"wait_us\": %ld, \"segments\": [",
               input.c_str(), r.chunks, r.threads, r.motion_frames, (unsigned long long)r.merge.n_timestamps,
               r.merge.do_cut, r.merge.time_removed, r.merge.saved_pct, r.seek_us, r.decode_us, r.analyze_us, r.init_us,
-              r.scan_wall_us, r.scan_work_us);
+              r.scan_wall_us, r.scan_work_us, r.copy_us, r.submit_us, r.wait_us);
   for (size_t i = 0; i < segs.size(); ++i)
     std::printf("%s[%.17g, %.17g]", i ? ", " : "", segs[i].start, segs[i].end);
   std::printf("]");
@@ -43,12 +84,14 @@ static void print_job(const std::string &input, const PipelineResult &r, const s
 int main(int argc, char **argv) {
   std::vector<std::string> files;
   int threads = 4, streams = 2;
+  long repeat = 1;
   std::string outdir = ".";
   for (int i = 1; i < argc; ++i) {
     if (!std::strcmp(argv[i], "--threads") && i + 1 < argc) threads = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--streams") && i + 1 < argc) streams = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--outdir") && i + 1 < argc) outdir = argv[++i];
     else if (!std::strcmp(argv[i], "--timestamps")) g_print_ts = true;
+    else if (!std::strcmp(argv[i], "--repeat") && i + 1 < argc) repeat = std::atol(argv[++i]);
     else files.push_back(argv[i]);
   }
   if (files.empty()) {
@@ -59,7 +102,10 @@ int main(int argc, char **argv) {
     if (files.size() == 1) {
       MtmvFile file(files[0]);
       PipelineResult r;
-      int rc = run_scan_pipeline([&] { return std::unique_ptr<FrameSource>(new MtmvSource(file)); }, threads, r);
+      int rc = run_scan_pipeline([&]() -> std::unique_ptr<FrameSource> {
+        if (repeat > 1) return std::unique_ptr<FrameSource>(new RepeatSource(file, (uint64_t)repeat));
+        return std::unique_ptr<FrameSource>(new MtmvSource(file));
+      }, threads, r);
       if (rc != 0) { std::fprintf(stderr, "error: %s\n", r.error.c_str()); return 1; }
       print_job(files[0], r, r.segments);
       return 0;

@@ -26,18 +26,24 @@
 #include "api_internal.h"
 
 struct mtgpu_batch {
-  // pinned host staging
-  unsigned char *h_mv = nullptr;
-  uint64_t *h_off = nullptr;
-  uint8_t *h_sd = nullptr;
+  // pinned host staging.  Offsets, has_sd bytes and records share ONE block
+  // ([off (cap_frames+1) x 8 | sd cap_frames | pad to 64 | records]) mirrored by one device
+  // block, so a batch goes up with a single H2D copy: with many decoder threads submitting
+  // concurrently the runtime's per-call cost, not PCIe, is what a submit pays for.
+  unsigned char *h_stage = nullptr;
+  unsigned char *h_mv = nullptr;     // = h_stage + hdr_bytes
+  uint64_t *h_off = nullptr;         // = h_stage
+  uint8_t *h_sd = nullptr;           // = h_stage + (cap_frames + 1) * 8
   double *h_pts = nullptr;
   uint64_t *h_tag = nullptr;
   uint8_t *h_flags = nullptr;
   // device mirrors
+  unsigned char *d_stage = nullptr;
   unsigned char *d_mv = nullptr;
   uint64_t *d_off = nullptr;
   uint8_t *d_sd = nullptr;
   uint8_t *d_flags = nullptr;
+  size_t hdr_bytes = 0;
   uint64_t cap_records = 0, n_records = 0;
   uint32_t cap_frames = 0, n_frames = 0;
   int rec_bytes = MT_COMPACT_BYTES;   // bytes per staged record: 8 (compact) or 40 (AoS)
@@ -65,15 +71,11 @@ using mtgpu::hip_fail;
 void free_batch(mtgpu_batch *b) {
   if (!b) return;
   if (b->stream) (void)hipStreamSynchronize(b->stream);
-  if (b->h_mv) (void)hipHostFree(b->h_mv);
-  if (b->h_off) (void)hipHostFree(b->h_off);
-  if (b->h_sd) (void)hipHostFree(b->h_sd);
+  if (b->h_stage) (void)hipHostFree(b->h_stage);
   if (b->h_pts) (void)hipHostFree(b->h_pts);
   if (b->h_tag) (void)hipHostFree(b->h_tag);
   if (b->h_flags) (void)hipHostFree(b->h_flags);
-  if (b->d_mv) (void)hipFree(b->d_mv);
-  if (b->d_off) (void)hipFree(b->d_off);
-  if (b->d_sd) (void)hipFree(b->d_sd);
+  if (b->d_stage) (void)hipFree(b->d_stage);
   if (b->d_flags) (void)hipFree(b->d_flags);
   if (b->done) (void)hipEventDestroy(b->done);
   if (b->stream) (void)hipStreamDestroy(b->stream);
@@ -86,20 +88,30 @@ void free_batch(mtgpu_batch *b) {
     if (_e != hipSuccess) { rc = hip_fail(_e, #expr); goto bad; }    \
   } while (0)
 
-// (Re)allocate the record staging of a batch for `records` records; the batch must be idle.
+// (Re)allocate the staging block of a batch for `records` records; the batch must be idle and
+// empty (cap_frames is already set).
 int alloc_records(mtgpu_batch *b, uint64_t records) {
   int rc = MT_OK;
-  if (b->h_mv) (void)hipHostFree(b->h_mv);
-  if (b->d_mv) (void)hipFree(b->d_mv);
-  b->h_mv = nullptr; b->d_mv = nullptr; b->cap_records = 0;
-  const size_t mvb = (size_t)records * (size_t)b->rec_bytes + 64;
-  PIPE_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_mv), mvb, hipHostMallocDefault));
-  PIPE_TRY(hipMalloc(reinterpret_cast<void **>(&b->d_mv), mvb));
+  if (b->h_stage) (void)hipHostFree(b->h_stage);
+  if (b->d_stage) (void)hipFree(b->d_stage);
+  b->h_stage = nullptr; b->d_stage = nullptr; b->cap_records = 0;
+  const size_t nf = (size_t)b->cap_frames;
+  b->hdr_bytes = (sizeof(uint64_t) * (nf + 1) + (nf + 1) + 63u) & ~(size_t)63u;
+  const size_t bytes = b->hdr_bytes + (size_t)records * (size_t)b->rec_bytes + 64;
+  PIPE_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_stage), bytes, hipHostMallocDefault));
+  PIPE_TRY(hipMalloc(reinterpret_cast<void **>(&b->d_stage), bytes));
+  b->h_off = reinterpret_cast<uint64_t *>(b->h_stage);
+  b->h_sd = b->h_stage + sizeof(uint64_t) * (nf + 1);
+  b->h_mv = b->h_stage + b->hdr_bytes;
+  b->d_off = reinterpret_cast<uint64_t *>(b->d_stage);
+  b->d_sd = b->d_stage + sizeof(uint64_t) * (nf + 1);
+  b->d_mv = b->d_stage + b->hdr_bytes;
+  b->h_off[0] = 0;
   b->cap_records = records;
   return MT_OK;
 bad:
-  if (b->h_mv) (void)hipHostFree(b->h_mv);
-  b->h_mv = nullptr;
+  if (b->h_stage) (void)hipHostFree(b->h_stage);
+  b->h_stage = nullptr; b->h_mv = nullptr; b->h_off = nullptr; b->h_sd = nullptr;
   return rc;
 }
 
@@ -112,23 +124,26 @@ int alloc_batch(mtgpu_batch **out, uint64_t max_records, uint32_t max_frames, in
   if ((rc = alloc_records(b, max_records)) != MT_OK) { free_batch(b); return rc; }
   {
     const size_t nf = (size_t)max_frames;
-    PIPE_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_off), sizeof(uint64_t) * (nf + 1), hipHostMallocDefault));
-    PIPE_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_sd), nf + 1, hipHostMallocDefault));
     PIPE_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_pts), sizeof(double) * (nf + 1), hipHostMallocDefault));
     PIPE_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_tag), sizeof(uint64_t) * (nf + 1), hipHostMallocDefault));
     PIPE_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_flags), nf + 1, hipHostMallocDefault));
-    PIPE_TRY(hipMalloc(reinterpret_cast<void **>(&b->d_off), sizeof(uint64_t) * (nf + 1)));
-    PIPE_TRY(hipMalloc(reinterpret_cast<void **>(&b->d_sd), nf + 1));
     PIPE_TRY(hipMalloc(reinterpret_cast<void **>(&b->d_flags), nf + 1));
     PIPE_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
     PIPE_TRY(hipEventCreateWithFlags(&b->done, hipEventDisableTiming));
   }
-  b->h_off[0] = 0;
   *out = b;
   return MT_OK;
 bad:
   free_batch(b);
   return rc;
+}
+
+// hipSetDevice only when this thread's current device differs (a submit per few hundred
+// microseconds from each of many threads: every runtime call counts).
+hipError_t use_device(int dev) {
+  int cur = -1;
+  if (hipGetDevice(&cur) == hipSuccess && cur == dev) return hipSuccess;
+  return hipSetDevice(dev);
 }
 
 }  // namespace
@@ -225,17 +240,16 @@ uint32_t mtgpu_batch_frames(const mtgpu_batch *b) { return b ? b->n_frames : 0; 
 int mtgpu_pipe_submit(mtgpu_pipe *p, mtgpu_batch *b) {
   if (!p || !b || b->owner != p) return fail(MT_ERR_INVALID, "batch does not belong to this pipe");
   if (b->state != 1) return fail(MT_ERR_INVALID, "batch is not being filled");
-  hipError_t e = hipSetDevice(mtgpu::ctx_device(p->ctx));
+  hipError_t e = use_device(mtgpu::ctx_device(p->ctx));
   if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
   hipStream_t st = b->stream;
   int rc = MT_OK;
   long nth;
   { std::lock_guard<std::mutex> lock(p->mu); nth = ++p->submits; }
   if (b->n_frames) {
-    if (b->n_records)
-      PIPE_TRY(hipMemcpyAsync(b->d_mv, b->h_mv, (size_t)b->n_records * (size_t)b->rec_bytes, hipMemcpyHostToDevice, st));
-    PIPE_TRY(hipMemcpyAsync(b->d_off, b->h_off, sizeof(uint64_t) * ((size_t)b->n_frames + 1), hipMemcpyHostToDevice, st));
-    PIPE_TRY(hipMemcpyAsync(b->d_sd, b->h_sd, b->n_frames, hipMemcpyHostToDevice, st));
+    // one copy: offsets + has_sd header and the records that follow it
+    PIPE_TRY(hipMemcpyAsync(b->d_stage, b->h_stage, b->hdr_bytes + (size_t)b->n_records * (size_t)b->rec_bytes,
+                            hipMemcpyHostToDevice, st));
     if (p->inject_submit_fail > 0 && nth == p->inject_submit_fail) {
       rc = fail(MT_ERR_DEVICE, "injected submit failure (MTGPU_INJECT_SUBMIT_FAIL)");
       goto bad;

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 runs of bench.py into the small files kept under profiles/.
+
+  pmc_summary.py stats  <kernel_stats.csv> <out.csv>            keep the rows of our kernels (+ top others)
+  pmc_summary.py pmc    <bench.json> <fetch_dir> <write_dir|-> <key> <out.json>
+        HBM bytes per scan_frames_kernel launch from separate --pmc FETCH_SIZE / WRITE_SIZE passes,
+        corrected as MI355X_MICROARCH.md "HBM" prescribes for gfx950 (counter unit KB; FETCH_SIZE x2),
+        next to the algorithmic bytes per launch that bench.py printed; merged into <out.json> under <key>.
+"""
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def find(d, suffix):
+    hits = glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True)
+    if not hits:
+        raise SystemExit(f"no *{suffix} under {d}")
+    return sorted(hits)[-1]
+
+
+def counter_mean(d, counter, kernel_substr="scan_frames_kernel"):
+    vals = []
+    with open(find(d, "_counter_collection.csv"), newline="") as fh:
+        for row in csv.DictReader(fh):
+            if row["Counter_Name"] == counter and kernel_substr in row["Kernel_Name"]:
+                vals.append(float(row["Counter_Value"]))
+    if not vals:
+        raise SystemExit(f"{counter}: no {kernel_substr} dispatches in {d}")
+    return sum(vals) / len(vals), len(vals)
+
+
+def main():
+    mode = sys.argv[1]
+    if mode == "stats":
+        src, dst = sys.argv[2], sys.argv[3]
+        rows = list(csv.reader(open(src, newline="")))
+        keep = [rows[0]] + [r for r in rows[1:] if "mtgpu::" in r[0]] + [r for r in rows[1:] if "mtgpu::" not in r[0]][:3]
+        csv.writer(open(dst, "w", newline="")).writerows(keep)
+        return
+    bench_json, fetch_dir, write_dir, key, out = sys.argv[2:7]
+    line = [ln for ln in open(bench_json) if ln.startswith("{")][-1]
+    b = json.loads(line)
+    alg = b["roofline"]["algorithmic_bytes_per_launch"]
+    f_kb, nf = counter_mean(fetch_dir, "FETCH_SIZE")
+    w_kb = None
+    if write_dir != "-":
+        w_kb, _ = counter_mean(write_dir, "WRITE_SIZE")
+    hbm = f_kb * 1024.0 * 2.0 + (w_kb * 1024.0 if w_kb is not None else 0.0)
+    rec = {"workload": b["config"]["workload"], "launches_averaged": nf, "FETCH_SIZE_KB_raw": f_kb,
+           "WRITE_SIZE_KB_raw": w_kb,
+           "correction": "gfx950: FETCH_SIZE x2 (MI355X_MICROARCH.md, HBM section); counter unit KB; FETCH_SIZE and "
+                         "WRITE_SIZE in separate --pmc passes",
+           "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": alg, "traffic_over_algorithmic": hbm / alg}
+    data = json.load(open(out)) if os.path.exists(out) else {}
+    data[key] = rec
+    json.dump(data, open(out, "w"), indent=1)
+    print(key, json.dumps(rec))
+
+
+if __name__ == "__main__":
+    main()
