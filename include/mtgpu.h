@@ -194,11 +194,14 @@ typedef struct mtgpu_batch mtgpu_batch;
 
 int mtgpu_pipe_create(mtgpu_ctx *ctx, uint64_t max_records_per_batch, uint32_t max_frames_per_batch,
                       int n_buffers, mtgpu_pipe **out);
-/* Staging layout of a pipe.  COMPACT8 (what mtgpu_pipe_create picks): add_frame copies only the
- * 8 bytes per record that the scan reads into pinned memory, so 5x fewer bytes cross PCIe and
- * HBM; AOS40: the 40-byte records are staged unchanged.  Results are identical. */
+/* Staging layout of a pipe.  COMPACT8: add_frame copies only the 8 bytes per record that the scan
+ * reads into pinned memory, so 5x fewer bytes cross PCIe; AOS40: the 40-byte records are staged
+ * unchanged.  mtgpu_pipe_create picks COMPACT8 | ZERO_COPY.  Results are identical. */
 #define MT_LAYOUT_COMPACT8 0
 #define MT_LAYOUT_AOS40 1
+/* OR-ed into either layout: no H2D / D2H copy commands — the scan kernel reads the pinned staging
+ * over PCIe itself and writes the flags into pinned memory (one launch + one event per batch). */
+#define MT_LAYOUT_ZERO_COPY 2
 int mtgpu_pipe_create_layout(mtgpu_ctx *ctx, uint64_t max_records_per_batch, uint32_t max_frames_per_batch,
                              int n_buffers, int layout, mtgpu_pipe **out);
 void mtgpu_pipe_destroy(mtgpu_pipe *pipe);

@@ -4,12 +4,12 @@ gap-bounded segment merge) as hand-written gfx950 HIP kernels behind the C ABI o
 include/mtgpu.h.  This package is the thin host-side mirror of the reference's
 scanner interface; the compute lives in libmtgpu.so (csrc/)."""
 from . import config, mvfile, mvjson
-from ._abi import (COMPACT_DTYPE, LAYOUT_AOS40, LAYOUT_COMPACT8, LIB_PATH, MERGE_PARAMS_DTYPE, MERGE_RESULT_DTYPE, MV_DTYPE, SEGMENT_DTYPE,
+from ._abi import (COMPACT_DTYPE, LAYOUT_AOS40, LAYOUT_COMPACT8, LAYOUT_ZERO_COPY, LIB_PATH, MERGE_PARAMS_DTYPE, MERGE_RESULT_DTYPE, MV_DTYPE, SEGMENT_DTYPE,
                    MtgpuError, load_library)
 from .scanner import (FrameBatch, MergeParams, MotionScanner, ScanParams, ScanPipe, filter_frames,
                       frame_skip, make_chunks, pack_records, results_from_bytes)
 
-__all__ = ["config", "mvfile", "mvjson", "LIB_PATH", "COMPACT_DTYPE", "LAYOUT_AOS40", "LAYOUT_COMPACT8",
+__all__ = ["config", "mvfile", "mvjson", "LIB_PATH", "COMPACT_DTYPE", "LAYOUT_AOS40", "LAYOUT_COMPACT8", "LAYOUT_ZERO_COPY",
            "pack_records", "MV_DTYPE", "SEGMENT_DTYPE", "MERGE_PARAMS_DTYPE",
            "MERGE_RESULT_DTYPE", "MtgpuError", "load_library", "FrameBatch", "MergeParams",
            "MotionScanner", "ScanParams", "ScanPipe", "filter_frames", "frame_skip", "make_chunks",

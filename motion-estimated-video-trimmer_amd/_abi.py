@@ -13,7 +13,7 @@ import numpy as np
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "libmtgpu.so")
 
-LAYOUT_COMPACT8, LAYOUT_AOS40 = 0, 1
+LAYOUT_COMPACT8, LAYOUT_AOS40, LAYOUT_ZERO_COPY = 0, 1, 2
 COMPACT_DTYPE = np.dtype([("src_x", "<i2"), ("src_y", "<i2"), ("dst_x", "<i2"), ("dst_y", "<i2")])
 MT_OK, MT_ERR_INVALID, MT_ERR_CAPACITY, MT_ERR_DEVICE, MT_ERR_NOMEM, MT_ERR_BUSY = 0, 1, 2, 3, 4, 5
 

@@ -63,13 +63,17 @@ struct Config {   // same variables, defaults and parse types as config.hpp:56-1
   // (default: 4 for the compact layout — 16 workers x 3 batches stay inside the host's L3, so the DMA
   //  engine reads staging from cache — and 16 for the 40-byte layout)
   static int batch_mib() {
-    const int v = env_i("MTGPU_BATCH_MB", staging_layout() == MT_LAYOUT_AOS40 ? 16 : 4);
+    const int v = env_i("MTGPU_BATCH_MB", (staging_layout() & MT_LAYOUT_AOS40) ? 16 : 4);
     return v < 1 ? 1 : v;
   }
   // not in the reference: staging layout of the host dispatcher (include/mtgpu.h), "aos40" or "compact8"
+  // ("aos40", "compact8", either with the suffix "_zc" for zero-copy)
   static int staging_layout() {
     const char *v = std::getenv("MTGPU_STAGING");
-    return (v && std::string(v) == "aos40") ? MT_LAYOUT_AOS40 : MT_LAYOUT_COMPACT8;
+    const std::string s = v ? v : "compact8_zc";
+    int layout = s.rfind("aos40", 0) == 0 ? MT_LAYOUT_AOS40 : MT_LAYOUT_COMPACT8;
+    if (s.size() > 3 && s.compare(s.size() - 3, 3, "_zc") == 0) layout |= MT_LAYOUT_ZERO_COPY;
+    return layout;
   }
 };
 
@@ -323,7 +327,7 @@ class GpuMotionScanner {   // public shape of MotionScanner (motion_scanner.hpp:
   bool initialize(uint64_t batch_records = 0, uint32_t batch_frames = 256, int n_buffers = 3) {
     if (batch_records == 0) {
       const uint64_t fine = (uint64_t)((src_.width() + 3) / 4) * (uint64_t)((src_.height() + 3) / 4);
-      const uint64_t rec_bytes = Config::staging_layout() == MT_LAYOUT_AOS40 ? MT_MV_BYTES : MT_COMPACT_BYTES;
+      const uint64_t rec_bytes = (Config::staging_layout() & MT_LAYOUT_AOS40) ? MT_MV_BYTES : MT_COMPACT_BYTES;
       batch_records = std::max<uint64_t>(2 * fine, ((uint64_t)Config::batch_mib() << 20) / rec_bytes);
     }
     if (!be_->ensure(src_.width(), src_.height(), device_, batch_records, batch_frames, n_buffers, err_)) return false;

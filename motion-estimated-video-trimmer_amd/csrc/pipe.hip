@@ -4,10 +4,15 @@
 // (reference src/motion_scanner.cpp:375-383) and the copy-out that the MV side
 // data's lifetime (:347) forces on any batched backend.
 //
-// Staging layout: MT_LAYOUT_COMPACT8 (default) copies only bytes 6..13 of every 40-byte
+// Staging layout: MT_LAYOUT_COMPACT8 (default, with MT_LAYOUT_ZERO_COPY) copies only bytes 6..13 of every 40-byte
 // AVMotionVector (src_x, src_y, dst_x, dst_y — all check_frame reads) into pinned memory, so
 // 8 instead of 40 bytes per record cross PCIe and the scan reads the 8-byte records
 // (scan_kernels.hip, REC 8); MT_LAYOUT_AOS40 stages the records unchanged.
+//
+// MT_LAYOUT_ZERO_COPY (either record layout): no device mirror and no copy commands at all — the
+// scan kernel streams the pinned block over PCIe itself (every record is read exactly once by
+// every plan, banded ones included, since bands replay a device-side queue) and writes the flag
+// bytes straight into pinned memory; a submit is then one kernel launch + one event record.
 //
 // Batch states: 0 free -> (acquire) 1 filling -> (submit) 2 in flight -> (collect) 3 collected
 // -> (release) 0.  A failed submit drains the batch's stream and leaves it in state 1 with its
@@ -47,6 +52,7 @@ struct mtgpu_batch {
   uint64_t cap_records = 0, n_records = 0;
   uint32_t cap_frames = 0, n_frames = 0;
   int rec_bytes = MT_COMPACT_BYTES;   // bytes per staged record: 8 (compact) or 40 (AoS)
+  bool zero_copy = false;             // the scan reads the pinned staging (and writes the flags) over PCIe itself
   hipStream_t stream = nullptr;
   hipEvent_t done = nullptr;
   int state = 0;   // 0 free, 1 filling, 2 in flight, 3 collected
@@ -56,6 +62,7 @@ struct mtgpu_batch {
 struct mtgpu_pipe {
   mtgpu_ctx *ctx = nullptr;
   int rec_bytes = MT_COMPACT_BYTES;
+  bool zero_copy = false;
   long inject_submit_fail = 0;   // MTGPU_INJECT_SUBMIT_FAIL=k (tests): the k-th submit fails after its copies were queued
   long submits = 0;
   std::vector<mtgpu_batch *> bufs;
@@ -76,7 +83,7 @@ void free_batch(mtgpu_batch *b) {
   if (b->h_tag) (void)hipHostFree(b->h_tag);
   if (b->h_flags) (void)hipHostFree(b->h_flags);
   if (b->d_stage) (void)hipFree(b->d_stage);
-  if (b->d_flags) (void)hipFree(b->d_flags);
+  if (b->d_flags && !b->zero_copy) (void)hipFree(b->d_flags);
   if (b->done) (void)hipEventDestroy(b->done);
   if (b->stream) (void)hipStreamDestroy(b->stream);
   delete b;
@@ -92,6 +99,7 @@ void free_batch(mtgpu_batch *b) {
 // empty (cap_frames is already set).
 int alloc_records(mtgpu_batch *b, uint64_t records) {
   int rc = MT_OK;
+  unsigned char *dev_view = nullptr;
   if (b->h_stage) (void)hipHostFree(b->h_stage);
   if (b->d_stage) (void)hipFree(b->d_stage);
   b->h_stage = nullptr; b->d_stage = nullptr; b->cap_records = 0;
@@ -99,13 +107,19 @@ int alloc_records(mtgpu_batch *b, uint64_t records) {
   b->hdr_bytes = (sizeof(uint64_t) * (nf + 1) + (nf + 1) + 63u) & ~(size_t)63u;
   const size_t bytes = b->hdr_bytes + (size_t)records * (size_t)b->rec_bytes + 64;
   PIPE_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_stage), bytes, hipHostMallocDefault));
-  PIPE_TRY(hipMalloc(reinterpret_cast<void **>(&b->d_stage), bytes));
+  if (b->zero_copy) {
+    // no device mirror: the kernel reads the pinned block through its device-visible address
+    PIPE_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&dev_view), b->h_stage, 0));
+  } else {
+    PIPE_TRY(hipMalloc(reinterpret_cast<void **>(&b->d_stage), bytes));
+    dev_view = b->d_stage;
+  }
   b->h_off = reinterpret_cast<uint64_t *>(b->h_stage);
   b->h_sd = b->h_stage + sizeof(uint64_t) * (nf + 1);
   b->h_mv = b->h_stage + b->hdr_bytes;
-  b->d_off = reinterpret_cast<uint64_t *>(b->d_stage);
-  b->d_sd = b->d_stage + sizeof(uint64_t) * (nf + 1);
-  b->d_mv = b->d_stage + b->hdr_bytes;
+  b->d_off = reinterpret_cast<uint64_t *>(dev_view);
+  b->d_sd = dev_view + sizeof(uint64_t) * (nf + 1);
+  b->d_mv = dev_view + b->hdr_bytes;
   b->h_off[0] = 0;
   b->cap_records = records;
   return MT_OK;
@@ -115,19 +129,21 @@ bad:
   return rc;
 }
 
-int alloc_batch(mtgpu_batch **out, uint64_t max_records, uint32_t max_frames, int rec_bytes) {
+int alloc_batch(mtgpu_batch **out, uint64_t max_records, uint32_t max_frames, int rec_bytes, bool zero_copy) {
   int rc = MT_OK;
   mtgpu_batch *b = new (std::nothrow) mtgpu_batch();
   if (!b) return fail(MT_ERR_NOMEM, "out of host memory");
   b->cap_frames = max_frames;
   b->rec_bytes = rec_bytes;
+  b->zero_copy = zero_copy;
   if ((rc = alloc_records(b, max_records)) != MT_OK) { free_batch(b); return rc; }
   {
     const size_t nf = (size_t)max_frames;
     PIPE_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_pts), sizeof(double) * (nf + 1), hipHostMallocDefault));
     PIPE_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_tag), sizeof(uint64_t) * (nf + 1), hipHostMallocDefault));
     PIPE_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_flags), nf + 1, hipHostMallocDefault));
-    PIPE_TRY(hipMalloc(reinterpret_cast<void **>(&b->d_flags), nf + 1));
+    if (zero_copy) PIPE_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&b->d_flags), b->h_flags, 0));
+    else PIPE_TRY(hipMalloc(reinterpret_cast<void **>(&b->d_flags), nf + 1));
     PIPE_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
     PIPE_TRY(hipEventCreateWithFlags(&b->done, hipEventDisableTiming));
   }
@@ -153,15 +169,15 @@ extern "C" {
 int mtgpu_pipe_create(mtgpu_ctx *ctx, uint64_t max_records_per_batch, uint32_t max_frames_per_batch,
                       int n_buffers, mtgpu_pipe **out) {
   return mtgpu_pipe_create_layout(ctx, max_records_per_batch, max_frames_per_batch, n_buffers,
-                                  MT_LAYOUT_COMPACT8, out);
+                                  MT_LAYOUT_COMPACT8 | MT_LAYOUT_ZERO_COPY, out);
 }
 
 int mtgpu_pipe_create_layout(mtgpu_ctx *ctx, uint64_t max_records_per_batch, uint32_t max_frames_per_batch,
                              int n_buffers, int layout, mtgpu_pipe **out) {
   if (!ctx || !out) return fail(MT_ERR_INVALID, "NULL argument");
   *out = nullptr;
-  if (layout != MT_LAYOUT_COMPACT8 && layout != MT_LAYOUT_AOS40)
-    return fail(MT_ERR_INVALID, "layout must be MT_LAYOUT_COMPACT8 or MT_LAYOUT_AOS40");
+  if (layout < 0 || layout > (MT_LAYOUT_AOS40 | MT_LAYOUT_ZERO_COPY))
+    return fail(MT_ERR_INVALID, "layout must be MT_LAYOUT_COMPACT8 or MT_LAYOUT_AOS40, optionally | MT_LAYOUT_ZERO_COPY");
   if (max_records_per_batch == 0 || max_frames_per_batch == 0 || n_buffers < 1 || n_buffers > 64)
     return fail(MT_ERR_INVALID, "pipe needs max_records > 0, max_frames > 0, 1 <= n_buffers <= 64");
   hipError_t e = hipSetDevice(mtgpu::ctx_device(ctx));
@@ -169,11 +185,12 @@ int mtgpu_pipe_create_layout(mtgpu_ctx *ctx, uint64_t max_records_per_batch, uin
   mtgpu_pipe *p = new (std::nothrow) mtgpu_pipe();
   if (!p) return fail(MT_ERR_NOMEM, "out of host memory");
   p->ctx = ctx;
-  p->rec_bytes = layout == MT_LAYOUT_AOS40 ? MT_MV_BYTES : MT_COMPACT_BYTES;
+  p->rec_bytes = (layout & MT_LAYOUT_AOS40) ? MT_MV_BYTES : MT_COMPACT_BYTES;
+  p->zero_copy = (layout & MT_LAYOUT_ZERO_COPY) != 0;
   if (const char *v = std::getenv("MTGPU_INJECT_SUBMIT_FAIL")) p->inject_submit_fail = std::atol(v);
   for (int i = 0; i < n_buffers; ++i) {
     mtgpu_batch *b = nullptr;
-    int rc = alloc_batch(&b, max_records_per_batch, max_frames_per_batch, p->rec_bytes);
+    int rc = alloc_batch(&b, max_records_per_batch, max_frames_per_batch, p->rec_bytes, p->zero_copy);
     if (rc != MT_OK) { mtgpu_pipe_destroy(p); return rc; }
     b->owner = p;
     p->bufs.push_back(b);
@@ -247,9 +264,10 @@ int mtgpu_pipe_submit(mtgpu_pipe *p, mtgpu_batch *b) {
   long nth;
   { std::lock_guard<std::mutex> lock(p->mu); nth = ++p->submits; }
   if (b->n_frames) {
-    // one copy: offsets + has_sd header and the records that follow it
-    PIPE_TRY(hipMemcpyAsync(b->d_stage, b->h_stage, b->hdr_bytes + (size_t)b->n_records * (size_t)b->rec_bytes,
-                            hipMemcpyHostToDevice, st));
+    // one copy: offsets + has_sd header and the records that follow it (zero-copy: none at all)
+    if (!b->zero_copy)
+      PIPE_TRY(hipMemcpyAsync(b->d_stage, b->h_stage, b->hdr_bytes + (size_t)b->n_records * (size_t)b->rec_bytes,
+                              hipMemcpyHostToDevice, st));
     if (p->inject_submit_fail > 0 && nth == p->inject_submit_fail) {
       rc = fail(MT_ERR_DEVICE, "injected submit failure (MTGPU_INJECT_SUBMIT_FAIL)");
       goto bad;
@@ -257,7 +275,8 @@ int mtgpu_pipe_submit(mtgpu_pipe *p, mtgpu_batch *b) {
     rc = mtgpu::ctx_launch_scan(p->ctx, b->d_mv, b->n_records, b->d_off, b->d_sd, b->n_frames, b->d_flags, st,
                                 b->rec_bytes);
     if (rc != MT_OK) goto bad;
-    PIPE_TRY(hipMemcpyAsync(b->h_flags, b->d_flags, b->n_frames, hipMemcpyDeviceToHost, st));
+    if (!b->zero_copy)
+      PIPE_TRY(hipMemcpyAsync(b->h_flags, b->d_flags, b->n_frames, hipMemcpyDeviceToHost, st));
   }
   PIPE_TRY(hipEventRecord(b->done, st));
   {

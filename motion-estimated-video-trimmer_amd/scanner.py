@@ -19,7 +19,7 @@ from typing import Iterable, List, Optional, Sequence, Tuple
 import numpy as np
 
 from . import _abi, config
-from ._abi import (COMPACT_DTYPE, LAYOUT_AOS40, LAYOUT_COMPACT8, MERGE_PARAMS_DTYPE, MERGE_RESULT_DTYPE,
+from ._abi import (COMPACT_DTYPE, LAYOUT_AOS40, LAYOUT_COMPACT8, LAYOUT_ZERO_COPY, MERGE_PARAMS_DTYPE, MERGE_RESULT_DTYPE,
                    MV_DTYPE, SEGMENT_DTYPE, MergeParamsC, MergeResultC, PlanC, ScanParamsC, check,
                    load_library)
 
@@ -352,9 +352,10 @@ class ScanPipe:
     (pts, flag, tag) in submission order."""
 
     def __init__(self, scanner: MotionScanner, max_records: int, max_frames: int, n_buffers: int = 3,
-                 layout: int = LAYOUT_COMPACT8):
-        """layout: LAYOUT_COMPACT8 (default; 8 of every 40 record bytes are staged and shipped)
-        or LAYOUT_AOS40 (records staged unchanged).  Results are identical."""
+                 layout: int = LAYOUT_COMPACT8 | LAYOUT_ZERO_COPY):
+        """layout: LAYOUT_COMPACT8 (8 of every 40 record bytes are staged) or LAYOUT_AOS40 (records
+        staged unchanged), optionally | LAYOUT_ZERO_COPY (the scan reads the pinned staging over
+        PCIe itself: no copy commands).  Default: compact + zero-copy.  Results are identical."""
         self._lib = scanner._lib
         self._scanner = scanner            # keeps the context alive
         self._pipe = C.c_void_p()

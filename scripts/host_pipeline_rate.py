@@ -28,7 +28,7 @@ with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") els
     m.mvfile.write_mtmv(path, 1920, 1080, 1, spec.tb_den, spec.fps, n / spec.fps, ticks, frames)
     size = os.path.getsize(path)
     rows = []
-    sweep = [("aos40", 16), ("compact8", 4)]
+    sweep = [("aos40", 16), ("compact8", 4), ("compact8_zc", 4), ("aos40_zc", 16)]
     if os.environ.get("RATE_SWEEP") == "1":
         sweep = [("aos40", 16), ("aos40", 4), ("compact8", 1), ("compact8", 2), ("compact8", 4), ("compact8", 8), ("compact8", 16)]
     for staging, batch_mb in sweep:
@@ -51,7 +51,7 @@ with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") els
                 if best is None or row["frames_per_s"] > best["frames_per_s"]:
                     best = row
             rows.append(best)
-            print(f"{staging:8s} batch={batch_mb:2d}MiB threads={threads:2d}  process {best['process_s']:5.2f} s | scan phase {best['scan_phase_s']:5.2f} s "
+            print(f"{staging:11s} batch={batch_mb:2d}MiB threads={threads:2d}  process {best['process_s']:5.2f} s | scan phase {best['scan_phase_s']:5.2f} s "
                   f"(worker init {best['worker_init_s']:.2f} s each) -> {best['frames_per_s']:8.0f} frames/s  "
                   f"{best['aos_GBps']:6.2f} GB/s of AVMotionVector bytes after init  (analyze {best['analyze_s_summed']:.2f} s summed = copy "
                   f"{best['copy_s_summed']:.2f} + submit {best['submit_s_summed']:.2f} + wait {best['gpu_wait_s_summed']:.2f}; "
@@ -65,7 +65,7 @@ with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") els
     m.mvfile.write_mtmv(hpath, 1920, 1080, 1, spec.tb_den, spec.fps, hot_n / spec.fps,
                         [spec.pts_ticks(i) for i in range(hot_n)], hframes, key=[1] * hot_n)
     reps = 1000
-    for staging, batch_mb in (("aos40", 16), ("compact8", 4)):
+    for staging, batch_mb in (("aos40", 16), ("compact8", 4), ("compact8_zc", 4), ("compact8_zc", 16), ("aos40_zc", 16)):
         env = dict(os.environ, CHUNK_DURATION_SEC="10", TARGET_FPS="0", MTGPU_STAGING=staging, MTGPU_BATCH_MB=str(batch_mb))
         for threads in (1, 4, 16):
             best = None
@@ -81,7 +81,7 @@ with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") els
                 if best is None or row["frames_per_s"] > best["frames_per_s"]:
                     best = row
             hot_rows.append(best)
-            print(f"hot source {staging:8s} threads={threads:2d} -> {best['frames_per_s']:8.0f} frames/s  {best['aos_GBps']:6.2f} GB/s of "
+            print(f"hot source {staging:11s} {batch_mb:2d}MiB threads={threads:2d} -> {best['frames_per_s']:8.0f} frames/s  {best['aos_GBps']:6.2f} GB/s of "
                   f"AVMotionVector bytes (copy {best['copy_s_summed']:.2f} + submit {best['submit_s_summed']:.2f} + wait "
                   f"{best['gpu_wait_s_summed']:.2f} s summed)", flush=True)
     outp = os.path.join(ROOT, "gpurun_out", "r02_host_pipeline_rate.json")

@@ -174,7 +174,7 @@ def test_frame_filter_hand_cases_python_host(gpu_scanner_factory, tmp_path):
     assert pooled == [f / 32.0 for f in pl["timestamps_frames"]]
 
 
-@pytest.mark.parametrize("staging", ["compact8", "aos40"])
+@pytest.mark.parametrize("staging", ["compact8", "aos40", "compact8_zc", "aos40_zc"])
 def test_frame_filter_hand_cases_cpp_host(tmp_path, staging):
     """The same case through the C++ host layer (GpuMotionScanner::scan_range, chunk workers,
     MtmvSource's backward seek): pooled timestamps == the hand-derived list, any worker count."""
@@ -416,7 +416,8 @@ def test_compact_records_match_aos_everywhere(gpu_scanner_factory):
         assert np.array_equal(scan_compact(s, mv, off, None), ob.scan_frames(p, mv, off, None))
 
 
-@pytest.mark.parametrize("layout", [m.LAYOUT_COMPACT8, m.LAYOUT_AOS40])
+@pytest.mark.parametrize("layout", [m.LAYOUT_COMPACT8, m.LAYOUT_AOS40, m.LAYOUT_COMPACT8 | m.LAYOUT_ZERO_COPY,
+                                    m.LAYOUT_AOS40 | m.LAYOUT_ZERO_COPY])
 def test_scan_pipe_layouts_and_oversize_frames(gpu_scanner_factory, layout):
     """Both staging layouts of the pinned pipe against the oracle, including a frame larger than a
     whole batch (the reference's check_frame accepts any record count: the pipe grows the batch)."""
@@ -509,7 +510,7 @@ def test_cpp_host_pipeline_4k_fine_and_failure_exit_code(tmp_path):
     mp = m.MergeParams(duration=n / spec.fps, max_gap_sec=0.2, padding_sec=0.1, min_savings_pct=5.0)
     pooled, (want_seg, want_res) = _reference_worker_loop(spec, frames, ticks, n / spec.fps, p, 0.5, 0.0, mp)
     assert len(pooled) >= 8 and len(want_seg) >= 2
-    for staging in ("compact8", "aos40"):
+    for staging in ("compact8", "aos40", "compact8_zc"):
         out = subprocess.run([exe, path, "--threads", "2"], check=True, capture_output=True, text=True,
                              env=dict(env, MTGPU_STAGING=staging)).stdout
         _check_job(json.loads(out), pooled, want_seg, want_res)
