@@ -39,7 +39,7 @@ HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; ~6
 # "other_workloads" (north_star: frames/s on 1080p AND 4K; config 5 = the 960x540 fine grid).
 OTHER_WORKLOADS = [("4k_dense8x8", "code_defaults", 1024, 40),
                    ("4k_fine", "code_defaults", 1024, 12),
-                   ("4k_fine", "shipped_env", 512, 12)]
+                   ("4k_fine", "shipped_env", 1024, 12)]
 
 
 def parse(argv=None):

@@ -145,7 +145,9 @@ int alloc_batch(mtgpu_batch **out, uint64_t max_records, uint32_t max_frames, in
     if (zero_copy) PIPE_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&b->d_flags), b->h_flags, 0));
     else PIPE_TRY(hipMalloc(reinterpret_cast<void **>(&b->d_flags), nf + 1));
     PIPE_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
-    PIPE_TRY(hipEventCreateWithFlags(&b->done, hipEventDisableTiming));
+    // system-scope release at the event: the flag bytes a zero-copy scan wrote into pinned memory
+    // are visible to the host thread that waits on it
+    PIPE_TRY(hipEventCreateWithFlags(&b->done, hipEventDisableTiming | hipEventReleaseToSystem));
   }
   *out = b;
   return MT_OK;

@@ -31,7 +31,7 @@ def test_soak_random_parity(gpu_scanner_factory):
             last_note = time.time()
             with open(os.path.join(prog_dir, "soak_progress.log"), "a") as fh:
                 fh.write(f"{time.strftime('%H:%M:%S')} seed {seed}: {done} configurations ok\n")
-        sh = int(rng.randint(2, 6))
+        sh = int(rng.randint(1 if it % 7 == 0 else 2, 6))        # shift 1: grids up to ~1900x1100 -> row bands
         w, h = int(rng.randint(64, 3900)), int(rng.randint(64, 2200))
         kw = dict(mv_threshold_sq=float(rng.choice([16.0, 4.0, 0.0, 9.5])), block_size=1 << sh, block_shift=sh,
                   vectors_needed=int(rng.choice([1, 1, 2, 2, 3, 4, 6, 12, 255])),
@@ -51,6 +51,22 @@ def test_soak_random_parity(gpu_scanner_factory):
         for _ in range(2):                              # twice: warm caches, reused workspaces
             got = s.check_frames(m.FrameBatch(mv, off, None, sd))
             assert np.array_equal(got, want), (seed, it, w, h, kw, s.plan)
+        if it % 3 == 0:                                 # the 8-byte compact layout, device-resident
+            import torch
+            rec = m.pack_records(mv)
+            d_rec = torch.from_numpy(rec.view(np.uint8).reshape(-1).copy()).cuda() if len(rec) else \
+                torch.zeros(8, dtype=torch.uint8, device="cuda")
+            got = s.check_frames_device_compact(d_rec[: len(rec) * 8], torch.from_numpy(off.astype(np.int64)).cuda(),
+                                                torch.from_numpy(sd).cuda()).cpu().numpy()
+            assert np.array_equal(got, want), ("compact", seed, it, w, h, kw, s.plan)
+        if it % 5 == 0:                                 # the pinned pipe (zero-copy compact staging)
+            pipe = m.ScanPipe(s, int(rng.choice([500, 5000, 50000])), int(rng.choice([1, 4, 32])), int(rng.choice([1, 2, 3])))
+            for f in range(n_frames):
+                fr = mv[int(off[f]):int(off[f + 1])]
+                pipe.feed(fr if sd[f] else None, float(f), tag=f)
+            out = pipe.drain()
+            pipe.close()
+            assert [fl for _, fl, _ in out] == want.tolist(), ("pipe", seed, it, w, h, kw, s.plan)
         s.close()
         done += 1
     assert done > 0
