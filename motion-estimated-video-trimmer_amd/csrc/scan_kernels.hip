@@ -115,6 +115,12 @@ __device__ __forceinline__ void bump(unsigned int *cnt, unsigned int cell, unsig
     const unsigned int bit = cell * FB;
     unsigned int *w = &cnt[bit >> 5];
     const unsigned int sh = bit & 31u;
+    if constexpr (MODE == MODE_UNARY && FB == 1) {
+      // one bit per cell (vectors_needed <= 1): "voted at least once" — a fire-and-forget ds_or,
+      // nothing to read back, nothing to wait for
+      if (cap != 0u) (void)atomicOr(w, 1u << sh);
+      return;
+    }
     unsigned int f = (*w >> sh) & FM;                        // once saturated: a plain read
     if constexpr (MODE == MODE_UNARY) {
       unsigned int j = (unsigned int)__popc(f);              // thermometer: bits 0..j-1 are set

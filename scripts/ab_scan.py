@@ -50,6 +50,8 @@ def main():
         spec.events = synth.scripted_events(spec, distinct)
         if pan:
             spec.events = [synth.Event(0, distinct, 0, 0, spec.cells_x, spec.cells_y, 9, 3)]
+        if os.environ.get("AB_QUIET") == "1":       # no record passes the threshold: the vote path never runs
+            spec.events, spec.salt_p, spec.oob_p = [], 0.0, 0.0
         mv, off, pts, sd = synth.gen_stream(spec, distinct)
         kw = dict(m.config.CODE_DEFAULTS)
         kw.update(gridkw)
