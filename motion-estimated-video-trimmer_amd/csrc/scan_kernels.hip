@@ -157,6 +157,7 @@ __device__ __forceinline__ unsigned int combine_words(unsigned int a, unsigned i
   if constexpr (MODE == MODE_ADD32) {
     return a + b;
   } else {
+    if constexpr (MODE == MODE_UNARY && FB == 1) return a | b;   // one bit per cell: the sum saturates at 1
     if (b == 0u) return a;
     if (a == 0u) return b;
     constexpr unsigned int FM = (1u << FB) - 1u;
