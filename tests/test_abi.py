@@ -77,3 +77,49 @@ def test_invalid_arguments_are_reported():
     bad = m.ScanParams.from_config(1920, 1080).to_c()
     bad.grid_w = 0
     assert lib.mtgpu_create(C.byref(bad), 0, C.byref(ctx)) == _abi.MT_ERR_INVALID
+
+
+def test_null_and_foreign_handles_are_rejected_without_a_device():
+    """Argument checks of every handle-taking entry point run before any HIP call: NULL contexts,
+    pipes, batches and communicators are MT_ERR_INVALID (never a crash), on a box with no GPU too."""
+    lib = m.load_library()
+    inv = _abi.MT_ERR_INVALID
+    null = C.c_void_p()
+    out = C.c_void_p()
+    mp = _abi.MergeParamsC(5.0, 0.5, 10.0, 5.0)
+    res = _abi.MergeResultC()
+    assert lib.mtgpu_get_plan(None, None) == inv and lib.mtgpu_get_params(None, None) == inv
+    assert lib.mtgpu_set_slices(None, 2) == inv
+    assert lib.mtgpu_scan_frames(None, None, None, None, 1, None) == inv
+    assert lib.mtgpu_scan_frames_device(None, None, 0, None, None, 1, None, None) == inv
+    assert lib.mtgpu_scan_frames_device_compact(None, None, 0, None, None, 1, None, None) == inv
+    assert lib.mtgpu_merge_segments(None, None, 0, C.byref(mp), 0, None, 0, C.byref(res)) == inv
+    assert lib.mtgpu_merge_timestamps_device(None, None, 0, C.byref(mp), 0, None, 0, None, None) == inv
+    assert lib.mtgpu_merge_streams_device(None, None, None, None, 1, None, 0, None, None, 0, None, None) == inv
+    assert lib.mtgpu_pipe_create(None, 100, 4, 2, C.byref(out)) == inv and not out.value
+    assert lib.mtgpu_pipe_create_layout(None, 100, 4, 2, 0, C.byref(out)) == inv
+    assert lib.mtgpu_pipe_acquire(None, C.byref(out)) == inv
+    assert lib.mtgpu_batch_add_frame(None, None, 0, 0, 0.0, 0) == inv and lib.mtgpu_batch_frames(None) == 0
+    assert lib.mtgpu_pipe_submit(None, None) == inv and lib.mtgpu_pipe_release(None, None) == inv
+    assert lib.mtgpu_pipe_collect(None, C.byref(out), None, None, None, None) == inv
+    assert lib.mtgpu_gather_segments(None, None, 16, None, None) == inv
+    assert lib.mtgpu_comm_create(0, 0, None, 0, C.byref(out)) == inv
+    assert lib.mtgpu_pack_records(None, 3, None) == inv and lib.mtgpu_pack_records(None, 0, None) == _abi.MT_OK
+    lib.mtgpu_pipe_destroy(None)
+    lib.mtgpu_destroy(None)
+    lib.mtgpu_comm_destroy(None)
+    del null
+
+
+def test_pack_records_known_answer():
+    """mtgpu_pack_records keeps bytes 6..13 of every 40-byte record, in order (host data movement)."""
+    import numpy as np
+    mv = np.zeros(3, dtype=m.MV_DTYPE)
+    mv["src_x"], mv["src_y"], mv["dst_x"], mv["dst_y"] = [1, -2, 32767], [3, -4, -32768], [5, -6, 7], [8, -9, 10]
+    mv["w"], mv["h"], mv["flags"], mv["motion_x"] = 255, 255, 2 ** 63, -1          # neighbours of the kept bytes
+    raw = mv.view(np.uint8).reshape(3, 40)
+    raw[:, 14:16] = 0xAB                                                            # padding after dst_y
+    got = m.pack_records(mv)
+    assert got.dtype == m.COMPACT_DTYPE and got.itemsize == 8
+    assert got["src_x"].tolist() == [1, -2, 32767] and got["dst_y"].tolist() == [8, -9, 10]
+    assert got.view(np.uint8).reshape(3, 8).tobytes() == raw[:, 6:14].tobytes()
