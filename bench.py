@@ -18,6 +18,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement), including
   roofline        — the scan kernel: algorithmic bytes / live HIP-event duration vs 8 TB/s
   cpu_baseline    — the C oracle timed on this host's cores on a bounded sample (N=1 only)
   other_workloads — (N=1 only) 4K 240x135 and 4K fine 960x540 scans, same measurement
+  host_fed        — (N=1 only) PCIe-inclusive frames/s of the C++ host pipeline (never `value`)
 """
 import argparse
 import json
@@ -56,6 +57,7 @@ def parse(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample budget (0 = skip)")
     ap.add_argument("--no-merge", action="store_true", help="time the scan kernel alone")
     ap.add_argument("--no-others", action="store_true", help="skip the other_workloads leg")
+    ap.add_argument("--no-host", action="store_true", help="skip the host-fed (PCIe-inclusive) leg")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --same-device rehearses the N>1 control flow on a 1-GPU box")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -191,6 +193,42 @@ def time_compact(w, steps, warmup=3):
         e1.record()
     torch.cuda.synchronize()
     return float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev])), flags.cpu().numpy()
+
+
+def host_fed_leg(spec, mv, off):
+    """PCIe-inclusive rate of the host dispatcher (never `value`): the C++ front end mtgpu_scan_file
+    fed by 16 worker threads from a 12-frame stream of the headline workload repeated 500x (MV
+    bytes cache-resident, as when a decoder thread has just written them), with the default
+    staging (8-byte compact records, zero-copy) and with round 1's path (40-byte records, H2D
+    copies).  Separate processes; a few seconds."""
+    import tempfile
+    import mvtrim_amd as m
+    exe = os.path.join(ROOT, "motion-estimated-video-trimmer_amd", "mtgpu_scan_file")
+    if not os.path.exists(exe):
+        return {"error": "mtgpu_scan_file not built"}
+    n, reps, workers = 12, 500, min(16, len(os.sched_getaffinity(0)))
+    frames = [mv[int(off[i]):int(off[i + 1])] for i in range(1, 1 + n)]       # P-frames 1..12 of the tile
+    out = {"source": f"{n}-frame 1080p dense8x8 stream repeated {reps}x ({n * reps} frames), cache-resident",
+           "workers": workers, "front_end": "mtgpu_scan_file (C++ host layer: chunks -> pinned pipe -> scan -> merge)"}
+    d = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    with tempfile.TemporaryDirectory(dir=d) as tmp:
+        path = os.path.join(tmp, "hot.mtmv")
+        m.mvfile.write_mtmv(path, 1920, 1080, 1, spec.tb_den, spec.fps, n / spec.fps,
+                            [spec.pts_ticks(i) for i in range(n)], frames, key=[1] * n)
+        for name, staging in (("compact8_zero_copy", "compact8_zc"), ("aos40_copy", "aos40")):
+            env = dict(os.environ, CHUNK_DURATION_SEC="10", TARGET_FPS="0", MTGPU_STAGING=staging)
+            env.pop("MTGPU_BATCH_MB", None)
+            best = 0.0
+            for _ in range(2):
+                r = subprocess.run([exe, path, "--threads", str(workers), "--repeat", str(reps)], capture_output=True,
+                                   text=True, env=env, timeout=120)
+                if r.returncode != 0:
+                    return dict(out, error=(r.stderr or "mtgpu_scan_file failed")[-300:])
+                j = json.loads(r.stdout)
+                best = max(best, n * reps / max(j["scan_work_us"] * 1e-6, 1e-9))
+            out[name + "_frames_per_s"] = best
+    out["speedup"] = out["compact8_zero_copy_frames_per_s"] / out["aos40_copy_frames_per_s"]
+    return out
 
 
 def roofline_of(alg_bytes, kern_ms):
@@ -381,12 +419,18 @@ def run_rank(a):
                 traffic = None
         cpu = None
         others = None
+        host = None
         # the batch is the generated tile repeated: so must be its flags (checks every frame of the
         # 5 GB batch, not only the first tile, against the oracle-verified tile flags below)
         tile_flags = flags_host[: a.distinct]
         assert np.array_equal(flags_host, np.tile(tile_flags, reps)[: a.frames]), "flags are not tile-periodic"
         if world == 1 and a.cpu_seconds > 0:
             cpu = cpu_baseline(params, mv, off, tile_flags, a.cpu_seconds, a.workload)
+        if world == 1 and not a.no_host and a.workload == "1080p_dense8x8":
+            try:
+                host = host_fed_leg(spec, mv, off)
+            except Exception as e:          # informational leg
+                host = {"error": repr(e)}
         if world == 1 and not a.no_others:
             del d_mv, d_off, w
             torch.cuda.empty_cache()
@@ -416,6 +460,7 @@ def run_rank(a):
             "roofline": roof,
             "cpu_baseline": cpu,
             "other_workloads": others,
+            "host_fed": host,
             "motion_frames_in_batch": int(flags_host.sum()),
         }
         print(json.dumps(line), flush=True)

@@ -17,7 +17,7 @@ for w in 1080p fine 4k; do
   i=0
   for p in "${PASSES[@]}"; do
     d=$O/${w}_$i
-    timeout -k 10 120 rocprofv3 --kernel-trace --pmc $p -f csv -d $d -- python3 bench.py ${WL[$w]} --steps 3 --warmup 1 --cpu-seconds 0 --no-others --no-merge > $d.log 2>&1 || { echo "pass $w $i failed"; tail -3 $d.log; }
+    timeout -k 10 120 rocprofv3 --kernel-trace --pmc $p -f csv -d $d -- python3 bench.py ${WL[$w]} --steps 3 --warmup 1 --cpu-seconds 0 --no-others --no-host --no-merge > $d.log 2>&1 || { echo "pass $w $i failed"; tail -3 $d.log; }
     i=$((i+1))
   done
 done

@@ -6,18 +6,18 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out
-HEAD="--steps 20 --warmup 3 --cpu-seconds 0 --no-others"
-FINE="--workload 4k_fine --params shipped_env --frames 1024 --steps 10 --warmup 2 --cpu-seconds 0 --no-others"
+HEAD="--steps 20 --warmup 3 --cpu-seconds 0 --no-others --no-host"
+FINE="--workload 4k_fine --params shipped_env --frames 1024 --steps 10 --warmup 2 --cpu-seconds 0 --no-others --no-host"
 run() { name=$1; shift; echo "== $name"; "$@" > $O/$name.log 2>&1 || { tail -5 $O/$name.log; exit 1; }; }
 
 run r02_prof_1080p rocprofv3 --kernel-trace --stats -f csv -d $O/r02_prof_1080p -- python3 bench.py $HEAD
 grep '^{' $O/r02_prof_1080p.log | tail -1 > $O/r02_bench_1080p_dense8x8.json
 run r02_prof_fine rocprofv3 --kernel-trace --stats -f csv -d $O/r02_prof_fine -- python3 bench.py $FINE
 grep '^{' $O/r02_prof_fine.log | tail -1 > $O/r02_bench_4k_fine_shipped_env.json
-run r02_pmc_fetch_1080p rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $O/r02_pmc_fetch_1080p -- python3 bench.py --steps 3 --warmup 1 --cpu-seconds 0 --no-others
-run r02_pmc_write_1080p rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d $O/r02_pmc_write_1080p -- python3 bench.py --steps 3 --warmup 1 --cpu-seconds 0 --no-others
-run r02_pmc_fetch_fine rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $O/r02_pmc_fetch_fine -- python3 bench.py --workload 4k_fine --params shipped_env --frames 1024 --steps 3 --warmup 1 --cpu-seconds 0 --no-others
-run r02_pmc_write_fine rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d $O/r02_pmc_write_fine -- python3 bench.py --workload 4k_fine --params shipped_env --frames 1024 --steps 3 --warmup 1 --cpu-seconds 0 --no-others
+run r02_pmc_fetch_1080p rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $O/r02_pmc_fetch_1080p -- python3 bench.py --steps 3 --warmup 1 --cpu-seconds 0 --no-others --no-host
+run r02_pmc_write_1080p rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d $O/r02_pmc_write_1080p -- python3 bench.py --steps 3 --warmup 1 --cpu-seconds 0 --no-others --no-host
+run r02_pmc_fetch_fine rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $O/r02_pmc_fetch_fine -- python3 bench.py --workload 4k_fine --params shipped_env --frames 1024 --steps 3 --warmup 1 --cpu-seconds 0 --no-others --no-host
+run r02_pmc_write_fine rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d $O/r02_pmc_write_fine -- python3 bench.py --workload 4k_fine --params shipped_env --frames 1024 --steps 3 --warmup 1 --cpu-seconds 0 --no-others --no-host
 run r02_prof_merge rocprofv3 --kernel-trace --stats -f csv -d $O/r02_prof_merge -- python3 scripts/merge_rate.py
 
 python3 scripts/pmc_summary.py stats "$(find $O/r02_prof_1080p -name "*_kernel_stats.csv" | tail -1)" $O/r02_1080p_dense8x8_kernel_stats.csv
