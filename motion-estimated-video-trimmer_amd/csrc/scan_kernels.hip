@@ -159,6 +159,50 @@ __device__ __forceinline__ unsigned int count_of(const unsigned int *cnt, unsign
   }
 }
 
+// Packed counter word -> one bit per field (32 / FB bits): is the cell active?
+template <int FB, int MODE>
+__device__ __forceinline__ unsigned int active_bits(unsigned int x, unsigned int vn) {
+  if constexpr (MODE == MODE_UNARY) {
+    // thermometer code: the field holds min(votes, vn) ones from bit 0 up, so the cell is active
+    // (>= vn votes) iff bit vn-1 of its field is set; vn == 0: every cell is active
+    x = vn ? (x >> (vn - 1u)) : 0xffffffffu;
+    if constexpr (FB == 2) {
+      x &= 0x55555555u; x = (x | (x >> 1)) & 0x33333333u; x = (x | (x >> 2)) & 0x0f0f0f0fu;
+      x = (x | (x >> 4)) & 0x00ff00ffu; x = (x | (x >> 8)) & 0x0000ffffu;
+    } else if constexpr (FB == 4) {
+      x &= 0x11111111u; x = (x | (x >> 3)) & 0x03030303u; x = (x | (x >> 6)) & 0x000f000fu;
+      x = (x | (x >> 12)) & 0x000000ffu;
+    } else if constexpr (FB == 8) {
+      x &= 0x01010101u; x = (x | (x >> 7)) & 0x00030003u; x = (x | (x >> 14)) & 0x0000000fu;
+    }
+    return x;
+  } else {                                   // binary fields (CAS8): count >= vn
+    constexpr unsigned int FM = (1u << FB) - 1u;
+    unsigned int r = 0u;
+#pragma unroll
+    for (int i = 0; i < 32 / FB; ++i) r |= ((((x >> (i * FB)) & FM) >= vn) ? 1u : 0u) << i;
+    return r;
+  }
+}
+
+// 64-bit activity mask of cells [firstcell, firstcell + ncell) of the tile (ncell <= 64).
+template <int FB, int MODE>
+__device__ __forceinline__ unsigned long long mask_word(const unsigned int *cnt, unsigned int firstcell, int ncell,
+                                                        unsigned int vn) {
+  constexpr int CPW = 32 / FB;               // cells per counter word
+  unsigned long long m = 0ull;
+  unsigned int wi = (firstcell * (unsigned int)FB) >> 5;
+  int rel = (int)(wi * (unsigned int)CPW) - (int)firstcell;       // <= 0: first cell of word wi, relative
+  while (rel < ncell) {
+    const unsigned long long bits = active_bits<FB, MODE>(cnt[wi], vn);
+    m |= (rel >= 0) ? (bits << rel) : (bits >> (-rel));
+    rel += CPW;
+    ++wi;
+  }
+  if (ncell < 64) m &= (1ull << ncell) - 1ull;
+  return m;
+}
+
 // Field-wise saturating sum of two packed counter words (slice combine).
 template <int FB, int MODE>
 __device__ __forceinline__ unsigned int combine_words(unsigned int a, unsigned int b, unsigned int cap) {
@@ -443,7 +487,8 @@ __global__ __launch_bounds__(BLOCK) void scan_frames_kernel(
     const int crows = c1 - c0;
     for (int q0r = 0; q0r < crows; q0r += k.chunk_rows) {
       const int qn = min(k.chunk_rows, crows - q0r);
-      {  // 2a: activity masks, one wave per (mask row, word)
+      if constexpr (FB == 32) {
+        // 2a (32-bit counters, small grids): one wave per (mask row, word): compare + ballot
         const int lane = tid & 63, wave = tid >> 6;
         const int ntask = (qn + 2) * W;
         for (int t = wave; t < ntask; t += BLOCK / 64) {
@@ -455,6 +500,20 @@ __global__ __launch_bounds__(BLOCK) void scan_frames_kernel(
             on = count_of<FB>(cnt, (unsigned int)((g - t0) * k.gw + x)) >= k.active_min;
           const unsigned long long m = __ballot(on);
           if (lane == 0) mask[(size_t)j * W + w] = m;
+        }
+      } else {
+        // 2a (packed counters, big grids): one LANE per (mask row, word) — it reads the 2*FB
+        // counter words that hold its 64 cells and squeezes the "active" bit of every field into
+        // the mask (the wave-per-word ballot form took 140 us per 960x540 frame: 17 % of the
+        // workgroup's life, un-overlapped whenever one workgroup owns the CU)
+        const int ntask = (qn + 2) * W;
+        for (int t = tid; t < ntask; t += BLOCK) {
+          const int j = t / W, w = t - j * W;
+          const int g = c0 + q0r - 1 + j;
+          unsigned long long m = 0ull;
+          if (g >= t0 && g < t1)
+            m = mask_word<FB, MODE>(cnt, (unsigned int)((g - t0) * k.gw + w * 64), min(64, k.gw - w * 64), k.vec_need);
+          mask[(size_t)j * W + w] = m;
         }
       }
       __syncthreads();
