@@ -169,15 +169,18 @@ int make_plan(mtgpu_ctx *c, int lds_max, int cu_count) {
       chunk_rows = (int)ch;
     } else {
       // 2nd choice: row bands walked by ONE workgroup per frame (scan_kernels.hip, SPILL): the
-      // records are still read once; later bands replay the queued votes.  Bands are therefore
-      // cheap, and a tile of at most half the LDS lets two workgroups share a CU (one streams
-      // while the other zeroes / runs its cluster test).  MTGPU_BAND_LDS_KB overrides the tile limit.
-      long tile_max = (long)lds_max / 2;
+      // records are still read once; later bands replay the queued votes.  As few, as large
+      // bands as LDS allows: one workgroup per CU then owns the CU's whole bandwidth, so a frame
+      // is finished (and the next one started) in half the time two co-resident workgroups would
+      // need — with 20 MB work units that halves the idle tail of a launch (960x540, 1024 frames:
+      // 2 bands 6.8 TB/s vs 4 bands 6.3-6.6), and every band less is one queue replay less on
+      // vote-heavy input (pan: 5.1 vs 4.1 TB/s).  MTGPU_BAND_LDS_KB overrides the tile limit.
+      long tile_max = (long)lds_max;
       const int fkb = env_int("MTGPU_BAND_LDS_KB", 0);
       if (fkb > 0) tile_max = (long)fkb * 1024 < (long)lds_max ? (long)fkb * 1024 : (long)lds_max;
       const size_t per_row = ((size_t)k.gw * (size_t)fb + 7u) / 8u + mask_row;
       long r = 0;
-      for (int pass = 0; pass < 2 && r < 1; ++pass) {             // half LDS first, all of it if a row is that wide
+      for (int pass = 0; pass < 2 && r < 1; ++pass) {             // the tile limit first, all of LDS if a row is that wide
         const long lim = pass == 0 ? tile_max : (long)lds_max;
         r = (lim - 64) / (long)per_row - 2;
         while (r >= 1 && lds_need((int)r, (int)r, k.gw, k.W, fb, nullptr) > (size_t)lim) --r;
@@ -217,8 +220,6 @@ int make_plan(mtgpu_ctx *c, int lds_max, int cu_count) {
   // 4 workgroups/CU (measured +2.5 % over 256 on 1080p); tiles above 48 KB run 1-2
   // workgroups/CU and take 16 waves each.
   int block = lds <= 48u * 1024u ? 512 : 1024;
-  // row bands (two <= 80 KB tiles per CU): 8 waves per workgroup measured +4 % over 16 (scripts/ab_scan.py, AB_SET=bands)
-  if (k.bands > 1) block = 512;
   const int fblock = env_int("MTGPU_FORCE_BLOCK", 0);
   if (fblock == 256 || fblock == 512 || fblock == 1024) block = fblock;
   c->plan.block_threads = block;
@@ -336,6 +337,13 @@ int ctx_launch_scan(mtgpu_ctx *c, const void *d_mv, uint64_t n_records, const ui
   return launch_scan_on(c, d_mv, n_records, d_off, d_sd, n_frames, d_flags, st, rec_bytes);
 }
 }  // namespace mtgpu
+
+#ifdef MTGPU_PHASE_TIMES
+namespace mtgpu { hipError_t debug_set_phase_times(unsigned long long *p); }
+extern "C" int mtgpu_debug_set_phase_times(void *p) {      // developer build only, not in include/mtgpu.h
+  return mtgpu::debug_set_phase_times(static_cast<unsigned long long *>(p)) == hipSuccess ? MT_OK : MT_ERR_DEVICE;
+}
+#endif
 
 extern "C" {
 

@@ -114,6 +114,22 @@ __device__ __forceinline__ MvFields decode(const u32x2 d) {
 
 enum { MODE_ADD32 = 0, MODE_UNARY = 1, MODE_CAS = 2 };
 
+// Developer build only (make EXTRA=-DMTGPU_PHASE_TIMES; scripts/phase_times.py): per-workgroup
+// timestamps (100 MHz wall clock) — [0] start, [1] end, then time spent in [2] zeroing, [3] streaming
+// records, [4] replaying the spill queue, [5] slice hand-off, [6] cluster test.  Compiled out otherwise.
+#ifdef MTGPU_PHASE_TIMES
+__device__ unsigned long long *g_phase_times = nullptr;
+#define PT_DECL unsigned long long pt_last = wall_clock64(), pt_acc[5] = {0, 0, 0, 0, 0}; \
+  if (g_phase_times && threadIdx.x == 0) g_phase_times[(size_t)item * 8] = pt_last
+#define PT_ADD(slot) do { const unsigned long long pt_now = wall_clock64(); pt_acc[slot] += pt_now - pt_last; pt_last = pt_now; } while (0)
+#define PT_FLUSH() do { if (g_phase_times && threadIdx.x == 0) { g_phase_times[(size_t)item * 8 + 1] = wall_clock64(); \
+  for (int q = 0; q < 5; ++q) g_phase_times[(size_t)item * 8 + 2 + q] = pt_acc[q]; } } while (0)
+#else
+#define PT_DECL do { } while (0)
+#define PT_ADD(slot) do { } while (0)
+#define PT_FLUSH() do { } while (0)
+#endif
+
 template <int FB, int MODE>
 __device__ __forceinline__ void bump(unsigned int *cnt, unsigned int cell, unsigned int cap) {
   if constexpr (MODE == MODE_ADD32) {
@@ -275,6 +291,7 @@ __global__ __launch_bounds__(BLOCK) void scan_frames_kernel(
   const int tid = threadIdx.x;
   const unsigned int item = item0 + blockIdx.x;
   // item -> frame, or (frame, slice): bands and slices are never both > 1
+  PT_DECL;
   const unsigned int f = SPILL ? item : item / (unsigned int)k.slices;
   const int slice = SPILL ? 0 : (int)(item - f * (unsigned int)k.slices);
 
@@ -323,6 +340,7 @@ __global__ __launch_bounds__(BLOCK) void scan_frames_kernel(
       if (band == 0 && tid == 0) { *total = 0u; *sq.tail = 0u; }
     }
     __syncthreads();
+    PT_ADD(0);
 
     // ---- phase 1
     if (band == 0) {                           // stream the records (HBM, exactly once per frame)
@@ -423,6 +441,7 @@ __global__ __launch_bounds__(BLOCK) void scan_frames_kernel(
       }
     }
     __syncthreads();
+    PT_ADD(band == 0 ? 1 : 2);
 
     // ---- slices: publish this partial grid; the LAST workgroup of the frame to arrive sums them
     // (no workgroup ever waits for another: nothing to deadlock on).  This is the guide's
@@ -460,7 +479,7 @@ __global__ __launch_bounds__(BLOCK) void scan_frames_kernel(
       if (tid == 0)
         *ticket = __hip_atomic_fetch_add(&tickets[f], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __syncthreads();
-      if (*ticket != (unsigned int)(k.slices - 1)) return;       // not the last: done
+      if (*ticket != (unsigned int)(k.slices - 1)) { PT_ADD(3); PT_FLUSH(); return; }   // not the last: done
       if (tid == 0) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -483,6 +502,7 @@ __global__ __launch_bounds__(BLOCK) void scan_frames_kernel(
       __syncthreads();
     }
 
+    PT_ADD(3);
     // ---- phase 2: chunks of centre rows [c0+q0, c0+q0+qn); mask row j <-> grid row c0+q0-1+j
     const int crows = c1 - c0;
     for (int q0r = 0; q0r < crows; q0r += k.chunk_rows) {
@@ -540,11 +560,13 @@ __global__ __launch_bounds__(BLOCK) void scan_frames_kernel(
       }
       __syncthreads();                                   // masks / counters are rewritten next
     }
+    PT_ADD(4);
   }
   if (local) atomicAdd(total, local);
   __syncthreads();
 
   if (tid == 0) flags[f] = (*total >= k.clust_need) ? 1 : 0;
+  PT_FLUSH();
 }
 
 // Calibration only: a pure streaming read shaped like the scan (one workgroup per contiguous
@@ -647,6 +669,10 @@ static hipError_t launch_block(const ScanLaunch &L) {
   if (L.rec_bytes == 8) return spill ? launch_form<BLOCK, 8, true>(L) : launch_form<BLOCK, 8, false>(L);
   return spill ? launch_form<BLOCK, 40, true>(L) : launch_form<BLOCK, 40, false>(L);
 }
+
+#ifdef MTGPU_PHASE_TIMES
+hipError_t debug_set_phase_times(unsigned long long *p) { return hipMemcpyToSymbol(HIP_SYMBOL(g_phase_times), &p, sizeof p); }
+#endif
 
 hipError_t launch_scan(const ScanLaunch &L) {
   if (L.n_frames == 0) return hipSuccess;

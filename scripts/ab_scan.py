@@ -15,7 +15,7 @@ import mvtrim_amd as m  # noqa: E402
 from bench import make_spec  # noqa: E402
 from mvtrim_amd import synth  # noqa: E402
 
-VARIANTS_FINE = [("default", dict()), ("chunk64", dict(MTGPU_FORCE_CHUNK="64")),
+VARIANTS_FINE = [("default", dict()), ("chunk64", dict(MTGPU_FORCE_CHUNK="64")), ("chunk128", dict(MTGPU_FORCE_CHUNK="128")),
                  ("chunk64/b1024", dict(MTGPU_FORCE_CHUNK="64", MTGPU_FORCE_BLOCK="1024")),
                  ("chunk32/b512", dict(MTGPU_FORCE_CHUNK="32", MTGPU_FORCE_BLOCK="512")),
                  ("chunk160/b512", dict(MTGPU_FORCE_CHUNK="160", MTGPU_FORCE_BLOCK="512")),
@@ -24,7 +24,9 @@ VARIANTS_KERNEL = [("v%d" % v, dict(MTGPU_VARIANT=str(v))) for v in (0, 1, 2, 4,
 VARIANTS_SLICES = [("auto", dict()), ("s1", dict(MTGPU_FORCE_SLICES="1")), ("s2", dict(MTGPU_FORCE_SLICES="2")),
                    ("s4", dict(MTGPU_FORCE_SLICES="4")), ("s8", dict(MTGPU_FORCE_SLICES="8"))]
 # row bands walked by one workgroup (spill queue): tile size / workgroup size (use with AB_VEC=4 on 4k_fine)
-VARIANTS_BANDS = [("auto", dict()), ("tile160", dict(MTGPU_BAND_LDS_KB="160")), ("tile80/b512", dict(MTGPU_FORCE_BLOCK="512")),
+VARIANTS_BANDS = [("auto", dict()), ("tile160", dict(MTGPU_BAND_LDS_KB="160")), ("tile160/b1024", dict(MTGPU_BAND_LDS_KB="160", MTGPU_FORCE_BLOCK="1024")),
+                  ("tile120/b1024", dict(MTGPU_BAND_LDS_KB="120", MTGPU_FORCE_BLOCK="1024")), ("tile80/b512", dict(MTGPU_FORCE_BLOCK="512")),
+                  ("tile80/b1024", dict(MTGPU_FORCE_BLOCK="1024")),
                   ("tile53", dict(MTGPU_BAND_LDS_KB="53")), ("tile53/b512", dict(MTGPU_BAND_LDS_KB="53", MTGPU_FORCE_BLOCK="512")),
                   ("tile40/b512", dict(MTGPU_BAND_LDS_KB="40", MTGPU_FORCE_BLOCK="512")),
                   ("tile120", dict(MTGPU_BAND_LDS_KB="120"))]
