@@ -508,18 +508,25 @@ __global__ __launch_bounds__(BLOCK) void scan_frames_kernel(
     for (int q0r = 0; q0r < crows; q0r += k.chunk_rows) {
       const int qn = min(k.chunk_rows, crows - q0r);
       if constexpr (FB == 32) {
-        // 2a (32-bit counters, small grids): one wave per (mask row, word): compare + ballot
-        const int lane = tid & 63, wave = tid >> 6;
+        // 2a (32-bit counters, small grids): one lane per (mask row, word); it visits its 64 cells
+        // in a lane-rotated order, so that the 64 lanes of a wave — whose words lie 64 counters
+        // apart — hit 64 different LDS banks in every step
+        const int lane = tid & 63;
         const int ntask = (qn + 2) * W;
-        for (int t = wave; t < ntask; t += BLOCK / 64) {
+        for (int t = tid; t < ntask; t += BLOCK) {
           const int j = t / W, w = t - j * W;
           const int g = c0 + q0r - 1 + j;                // grid row of this mask row
-          const int x = w * 64 + lane;
-          bool on = false;
-          if (g >= t0 && g < t1 && x < k.gw)             // outside the grid = inactive
-            on = count_of<FB>(cnt, (unsigned int)((g - t0) * k.gw + x)) >= k.active_min;
-          const unsigned long long m = __ballot(on);
-          if (lane == 0) mask[(size_t)j * W + w] = m;
+          unsigned long long m = 0ull;
+          if (g >= t0 && g < t1) {                       // outside the grid = inactive
+            const unsigned int *row = cnt + (size_t)(g - t0) * k.gw + w * 64;
+            const int ncell = min(64, k.gw - w * 64);
+#pragma unroll 8
+            for (int c = 0; c < 64; ++c) {
+              const int cc = (c + lane) & 63;
+              if (cc < ncell && row[cc] >= k.active_min) m |= 1ull << cc;
+            }
+          }
+          mask[(size_t)j * W + w] = m;
         }
       } else {
         // 2a (packed counters, big grids): one LANE per (mask row, word) — it reads the 2*FB
