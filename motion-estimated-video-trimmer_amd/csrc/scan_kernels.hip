@@ -508,25 +508,30 @@ __global__ __launch_bounds__(BLOCK) void scan_frames_kernel(
     for (int q0r = 0; q0r < crows; q0r += k.chunk_rows) {
       const int qn = min(k.chunk_rows, crows - q0r);
       if constexpr (FB == 32) {
-        // 2a (32-bit counters, small grids): one lane per (mask row, word); it visits its 64 cells
-        // in a lane-rotated order, so that the 64 lanes of a wave — whose words lie 64 counters
-        // apart — hit 64 different LDS banks in every step
+        // 2a (32-bit counters, small grids): FOUR lanes per (mask row, word), 16 cells each, joined
+        // by two xor-shuffles.  Cells are visited in a rotated order so that the 64 lanes of a wave
+        // (16 words that lie 64 counters apart x 4 quarters) hit 64 different LDS banks per step.
         const int lane = tid & 63;
-        const int ntask = (qn + 2) * W;
-        for (int t = tid; t < ntask; t += BLOCK) {
-          const int j = t / W, w = t - j * W;
+        const int sub = lane & 3, rot = (lane >> 2) & 15;
+        const int ntask = (qn + 2) * W * 4;
+        for (int t0q = 0; t0q < ntask; t0q += BLOCK) {             // uniform trip count: shuffles below
+          const int t = t0q + tid;
+          const int tw = t >> 2;
+          const int j = tw / W, w = tw - j * W;
           const int g = c0 + q0r - 1 + j;                // grid row of this mask row
           unsigned long long m = 0ull;
-          if (g >= t0 && g < t1) {                       // outside the grid = inactive
-            const unsigned int *row = cnt + (size_t)(g - t0) * k.gw + w * 64;
-            const int ncell = min(64, k.gw - w * 64);
-#pragma unroll 8
-            for (int c = 0; c < 64; ++c) {
-              const int cc = (c + lane) & 63;
-              if (cc < ncell && row[cc] >= k.active_min) m |= 1ull << cc;
+          if (t < ntask && g >= t0 && g < t1) {          // outside the grid = inactive
+            const unsigned int *row = cnt + (size_t)(g - t0) * k.gw + w * 64 + sub * 16;
+            const int ncell = min(64, k.gw - w * 64) - sub * 16;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+              const int cc = (c + rot) & 15;
+              if (cc < ncell && row[cc] >= k.active_min) m |= 1ull << (sub * 16 + cc);
             }
           }
-          mask[(size_t)j * W + w] = m;
+          m |= __shfl_xor(m, 1);
+          m |= __shfl_xor(m, 2);
+          if (t < ntask && sub == 0) mask[(size_t)j * W + w] = m;
         }
       } else {
         // 2a (packed counters, big grids): one LANE per (mask row, word) — it reads the 2*FB
