@@ -82,6 +82,10 @@ typedef struct mtgpu_plan {
   int32_t _pad;
 } mtgpu_plan;
 int mtgpu_get_plan(const mtgpu_ctx *ctx, mtgpu_plan *out);
+/* The plan mtgpu_create would choose on a device with `lds_bytes_per_workgroup` of LDS (gfx950:
+ * 163840) and `cu_count` CUs — pure host arithmetic, no device needed (capacity planning, tests). */
+int mtgpu_plan_preview(const mt_scan_params *params, int lds_bytes_per_workgroup, int cu_count,
+                       mtgpu_plan *out);
 
 /* Workgroups per frame along the record array: 0 = automatic (the default: split frames only
  * when a batch has too few frames to fill the chip and the frames are large), or 1, 2, 4, 8.

@@ -422,6 +422,23 @@ int mtgpu_get_params(const mtgpu_ctx *c, mt_scan_params *out) {
   return MT_OK;
 }
 
+int mtgpu_plan_preview(const mt_scan_params *params, int lds_bytes_per_workgroup, int cu_count, mtgpu_plan *out) {
+  if (!out) return fail(MT_ERR_INVALID, "out is NULL");
+  int rc = validate_params(params);
+  if (rc != MT_OK) return rc;
+  if (lds_bytes_per_workgroup < 1024 || cu_count < 1) return fail(MT_ERR_INVALID, "LDS size / CU count out of range");
+  mtgpu_ctx *tmp = new (std::nothrow) mtgpu_ctx();          // host object only: no HIP call is made
+  if (!tmp) return fail(MT_ERR_NOMEM, "out of host memory");
+  tmp->params = *params;
+  tmp->device = -1;
+  tmp->stream = nullptr;
+  tmp->lds_max = lds_bytes_per_workgroup;
+  rc = make_plan(tmp, lds_bytes_per_workgroup, cu_count);
+  if (rc == MT_OK) *out = tmp->plan;
+  delete tmp;
+  return rc;
+}
+
 int mtgpu_get_plan(const mtgpu_ctx *c, mtgpu_plan *out) {
   if (!c || !out) return fail(MT_ERR_INVALID, "NULL argument");
   *out = c->plan;

@@ -159,6 +159,15 @@ def _ptr(a: Optional[np.ndarray]):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+def plan_preview(params: "ScanParams", lds_bytes: int = 163840, cu_count: int = 256) -> dict:
+    """The launch plan the library would pick for `params` on a device with that much LDS per
+    workgroup and that many CUs (defaults: MI355X).  Host arithmetic only: works without a GPU."""
+    p = PlanC()
+    c = params.to_c()
+    check(load_library().mtgpu_plan_preview(C.byref(c), int(lds_bytes), int(cu_count), C.byref(p)))
+    return {n: getattr(p, n) for n, _ in PlanC._fields_ if not n.startswith("_")}
+
+
 def pack_records(mv: np.ndarray) -> np.ndarray:
     """40-byte AVMotionVector records -> the 8-byte compact records the host dispatcher stages
     (bytes 6..13: src_x, src_y, dst_x, dst_y) through the library's own packer (mtgpu_pack_records)."""

@@ -110,3 +110,56 @@ def test_sharding_helpers():
     assert cuts[0][0] == 0 and cuts[-1][1] == 10 and all(cuts[i][1] == cuts[i + 1][0] for i in range(3))
     recs = [int(off[b] - off[a]) for a, b in cuts]
     assert sum(recs) == 1000 and max(recs) <= 500
+
+
+def test_launch_planner_known_answers_and_invariants(monkeypatch):
+    """mtgpu_plan_preview: the launch planner (counter form, tile / band geometry, workgroup size)
+    is host arithmetic — checked here without a GPU for the MI355X limits (160 KB LDS, 256 CUs)."""
+    for k in ("MTGPU_FORCE_FB", "MTGPU_FORCE_BLOCK", "MTGPU_FORCE_CHUNK", "MTGPU_BAND_LDS_KB", "MTGPU_MAX_TILE_KB"):
+        monkeypatch.delenv(k, raising=False)
+    fine = dict(block_size=4, block_shift=2)
+    cases = [
+        ((1920, 1080, {}), dict(counter_bits=32, counter_mode=0, bands=1, block_threads=512, band_rows=62)),
+        ((3840, 2160, {}), dict(counter_bits=32, counter_mode=0, bands=1, block_threads=1024, band_rows=123)),
+        ((3840, 2160, dict(fine, vectors_needed=1)), dict(counter_bits=1, counter_mode=1, bands=1, band_rows=486)),
+        ((3840, 2160, dict(fine, vectors_needed=2)), dict(counter_bits=2, counter_mode=1, bands=1, band_rows=486)),
+        ((3840, 2160, dict(fine, vectors_needed=4)), dict(counter_bits=4, counter_mode=1, bands=2, band_rows=243)),
+        ((3840, 2160, dict(fine, vectors_needed=9)), dict(counter_bits=8, counter_mode=2)),           # 8-bit CAS fields
+        ((1920, 1080, dict(vectors_needed=200)), dict(counter_bits=32, bands=1)),                     # u32 counts: no packing needed
+    ]
+    for (w, h, kw), want in cases:
+        plan = m.plan_preview(m.ScanParams.from_config(w, h, **kw))
+        for key, v in want.items():
+            assert plan[key] == v, (w, h, kw, key, plan)
+    # the 1080p tile: 64 counter rows x 120 cells x 4 B + 64 mask rows x 2 words x 8 B + control words
+    p1080 = m.plan_preview(m.ScanParams.from_config(1920, 1080))
+    assert p1080["lds_bytes"] == 64 * 120 * 4 + 64 * 2 * 8 + 16 == 31760
+    # invariants over random legal grids and every VECTORS_NEEDED: the automatic plan always exists
+    # (MT_ERR_CAPACITY is unreachable), fits LDS, covers every analysed row, and a thermometer field
+    # is never narrower than VECTORS_NEEDED
+    rng = np.random.RandomState(7)
+    for _ in range(400):
+        sh = int(rng.randint(0, 7))
+        w, h = int(rng.randint(1, 32767) << sh) if rng.rand() < 0.1 else int(rng.randint(8, 8000)), int(rng.randint(8, 5000))
+        vn = int(rng.choice([0, 1, 2, 3, 4, 5, 8, 9, 64, 255]))
+        try:
+            p = m.ScanParams.from_config(w, h, block_size=1 << sh, block_shift=sh, vectors_needed=vn,
+                                         vertical_mask=float(rng.choice([0.0, 0.05, 0.3])))
+        except m.MtgpuError:
+            continue                                          # grid beyond int16: rejected before planning
+        plan = m.plan_preview(p)
+        rows = max(1, p.grid_h - 2 * p.vertical_margin)
+        assert 0 < plan["lds_bytes"] <= 163840, (w, h, sh, vn, plan)
+        assert plan["bands"] * plan["band_rows"] >= rows and (plan["bands"] - 1) * plan["band_rows"] < rows
+        assert 1 <= plan["chunk_rows"] <= plan["band_rows"] and plan["block_threads"] in (256, 512, 1024)
+        if plan["counter_mode"] == 1:
+            assert plan["counter_bits"] >= vn and plan["counter_bits"] in (1, 2, 4, 8)
+        if plan["counter_mode"] == 2:
+            assert plan["counter_bits"] == 8 and vn > 8
+    # a smaller LDS (64 KB parts) only changes the geometry, never the validity
+    small = m.plan_preview(m.ScanParams.from_config(3840, 2160), lds_bytes=65536, cu_count=104)
+    assert small["lds_bytes"] <= 65536 and small["counter_bits"] in (1, 2, 4, 8, 32)
+    with pytest.raises(m.MtgpuError):
+        bad = m.ScanParams.from_config(1920, 1080)
+        bad.grid_w = 0
+        m.plan_preview(bad)
