@@ -16,9 +16,11 @@
  * path include <libavcodec/avcodec.h>, which this image lacks, so the reference
  * object code cannot be built here without writing stand-in headers (not done).
  * What pins this file instead: hand-derived known-answer vectors in
- * tests/golden/ (each derivable by reading the cited reference lines), and the
- * two segment values SURVEY.md §8c recorded from a run of the reference's own
- * object code during the survey (tests/golden/survey_segments.json).
+ * tests/golden/ (each derivable by reading the cited reference lines), the
+ * behaviour the reference documents in the comments of its config/motion_trim.env
+ * (tests/golden/reference_documented_examples.json), and the two segment values
+ * SURVEY.md §8c recorded from a run of the reference's own object code during
+ * the survey (tests/golden/survey_segments.json).
  */
 #ifndef MT_ORACLE_H
 #define MT_ORACLE_H

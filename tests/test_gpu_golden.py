@@ -132,6 +132,22 @@ def test_merge_reproduces_survey_recorded_segments_on_gpu(gpu_scanner_factory):
         assert [["%.17g" % a, "%.17g" % b] for a, b in seg.tolist()] == g["segments_printed_17g"]
 
 
+def test_reference_documented_examples_on_gpu(gpu_scanner_factory):
+    """The behaviour the reference documents in config/motion_trim.env
+    (tests/golden/reference_documented_examples.json) through the HIP path."""
+    import documented_examples as de
+    scanners = {}
+
+    def check_frames(p, frames):
+        key = (p.mv_threshold_sq, p.vectors_needed, p.clusters_needed, p.vertical_margin, p.block_shift)
+        if key not in scanners:
+            scanners[key] = gpu_scanner_factory(p)
+        return scanners[key].check_frames(m.FrameBatch.from_frames(frames))
+    s0 = gpu_scanner_factory(m.ScanParams.from_config(1920, 1080))
+    de.run(lambda w, h, **kw: m.ScanParams.from_config(w, h, **kw), check_frames,
+           lambda ts, mp, job: s0.merge_segments(ts, mp, job), m.frame_skip)
+
+
 # ------------------------------------------------------------------ a6 / a7 hand cases
 
 def _filter_golden_stream(tmp_path):

@@ -225,6 +225,20 @@ def test_frame_filter_hand_cases():
     assert pooled == pl["timestamps_frames"]
 
 
+def test_reference_documented_examples():
+    """tests/golden/reference_documented_examples.json: the behaviour the reference documents in its
+    own config/motion_trim.env (threshold = "detects movement >= N pixels", cluster = "active block
+    with an adjacent active neighbour", VERTICAL_MASK percentages, TARGET_FPS, gap / padding /
+    savings) holds for the oracle."""
+    import documented_examples as de
+
+    def check_frames(p, frames):
+        b = m.FrameBatch.from_frames(frames)
+        return ob.scan_frames(p, b.mv, b.frame_off, b.has_sd)
+    de.run(lambda w, h, **kw: ob.params_from_config(w, h, **kw), check_frames,
+           lambda ts, mp, job: ob.pool_and_merge(ts, mp, job), lambda fps, t: ob.lib().mto_frame_skip(fps, t))
+
+
 # ------------------------------------------------------------------ property-based cross-check
 
 def test_oracle_vs_numpy_model_hypothesis():
