@@ -9,8 +9,9 @@
 //             REC 8: the compact src_x,src_y,dst_x,dst_y form the host dispatcher stages),
 //            threshold on |d|^2, map dst to a cell, vote in LDS     (:242-268)
 //   phase 2  per chunk of rows:
-//     2a     one wave per (row, 64-cell word): `count >= vectors_needed`
-//            -> __ballot -> 64-bit row masks in LDS                  (:282)
+//     2a     64-bit row masks of active cells (`count >= vectors_needed`, :282) in LDS: four
+//            lanes per mask word on 32-bit counters, one lane per word (bit-squeeze of the
+//            fields) on packed counters
 //     2b     one lane per (row, word): shifted-mask 4-neighbour test,
 //            __popcll, LDS reduction                                 (:277-293)
 //   compare the centre count with max(1, clusters_needed)           (:288)
@@ -25,6 +26,7 @@
 //            moves to the next one.  No retry loop on contention (same-word ORs are
 //            serialised by the LDS unit), at most vectors_needed ORs per vote, and a
 //            saturated field costs one plain read.  cell active <=> bit vectors_needed-1 set.
+//            FB = 1 is a plain fire-and-forget `ds_or_b32`.
 //   CAS8     FB = 8 binary field saturating at vectors_needed (9..255) via compare-and-swap.
 //            Only for unusually large VECTORS_NEEDED on grids too big for 32-bit counters.
 //   Packed forms need 32x..4x less LDS, so big grids (960x540) stay in one LDS tile and
@@ -162,16 +164,6 @@ __device__ __forceinline__ void bump(unsigned int *cnt, unsigned int cell, unsig
         old = seen;
       }
     }
-  }
-}
-
-template <int FB>
-__device__ __forceinline__ unsigned int count_of(const unsigned int *cnt, unsigned int cell) {
-  if constexpr (FB == 32) {
-    return cnt[cell];
-  } else {
-    const unsigned int bit = cell * FB;
-    return (cnt[bit >> 5] >> (bit & 31u)) & ((1u << FB) - 1u);
   }
 }
 
