@@ -255,8 +255,13 @@ __device__ __forceinline__ void vote(const MvFields m, const ScanK &k, int t0, i
       (unsigned long long)(dx * dx) + (unsigned long long)(dy * dy);
   const int gx = m.dst_x >> k.shift;
   const int gy = m.dst_y >> k.shift;
-  const bool in = (mag >= k.thr) & (gx >= 0) & (gx < k.gw) & (gy >= k.y_lo) & (gy < k.y_hi);
-  if (in & (gy >= t0) & (gy < t1)) bump<FB, MODE>(cnt, (unsigned int)((gy - t0) * k.gw + gx), k.vec_need);
+  // 0 <= gx < gw and y_lo <= gy < y_hi (:262) as two unsigned compares (y_hi >= y_lo by construction)
+  const bool in = (mag >= k.thr) & ((unsigned int)gx < (unsigned int)k.gw) &
+                  ((unsigned int)(gy - k.y_lo) < (unsigned int)(k.y_hi - k.y_lo));
+  // a single tile tracks every analysed row; only a band (SPILL) has to test its own rows
+  bool mine = in;
+  if constexpr (SPILL) mine = in & ((unsigned int)(gy - t0) < (unsigned int)(t1 - t0));
+  if (mine) bump<FB, MODE>(cnt, (unsigned int)((gy - t0) * k.gw + gx), k.vec_need);
   if constexpr (SPILL) {
     // wave-aggregated append: one returning LDS add per wave instruction, contiguous stores
     const bool qv = in & (gy >= sq.q_lo);
