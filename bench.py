@@ -209,7 +209,7 @@ def host_fed_leg(spec, mv, off):
     n, reps, workers = 12, 500, min(16, len(os.sched_getaffinity(0)))
     frames = [mv[int(off[i]):int(off[i + 1])] for i in range(1, 1 + n)]       # P-frames 1..12 of the tile
     out = {"source": f"{n}-frame 1080p dense8x8 stream repeated {reps}x ({n * reps} frames), cache-resident",
-           "workers": workers, "front_end": "mtgpu_scan_file (C++ host layer: chunks -> pinned pipe -> scan -> merge)"}
+           "workers": workers, "gpus": 1, "front_end": "mtgpu_scan_file (C++ host layer: chunks -> pinned pipe -> scan -> merge)"}
     d = "/dev/shm" if os.path.isdir("/dev/shm") else None
     with tempfile.TemporaryDirectory(dir=d) as tmp:
         path = os.path.join(tmp, "hot.mtmv")
@@ -218,6 +218,8 @@ def host_fed_leg(spec, mv, off):
         for name, staging in (("compact8_zero_copy", "compact8_zc"), ("aos40_copy", "aos40")):
             env = dict(os.environ, CHUNK_DURATION_SEC="10", TARGET_FPS="0", MTGPU_STAGING=staging)
             env.pop("MTGPU_BATCH_MB", None)
+            # one GPU only (the host layer would spread its workers over every visible device)
+            env["HIP_VISIBLE_DEVICES"] = (os.environ.get("HIP_VISIBLE_DEVICES") or "0").split(",")[0]
             best = 0.0
             for _ in range(2):
                 r = subprocess.run([exe, path, "--threads", str(workers), "--repeat", str(reps)], capture_output=True,
