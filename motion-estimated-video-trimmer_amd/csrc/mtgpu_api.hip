@@ -78,6 +78,7 @@ struct mtgpu_ctx {
   int wide_chunk_rows = 0, wide_lds_bytes = 0;   // single-workgroup-per-CU layout (see make_plan)
   int item_chunk = 0;    // MTGPU_ITEM_CHUNK (tests): work items per kernel launch, 0 = 2^30
   int lds_max = 0;       // device limit of LDS per workgroup
+  int group_request = 0; // MTGPU_GROUP: frames per workgroup, 0 = automatic
   uint64_t merge_large_min = 4096;   // timestamp lists at least this long take the multi-workgroup merge (MTGPU_MERGE_LARGE_MIN)
   std::mutex mu;         // guards the staging buffers below
   DevBuf d_mv, d_off, d_sd, d_flags, d_misc;
@@ -236,6 +237,8 @@ int make_plan(mtgpu_ctx *c, int lds_max, int cu_count) {
     c->slices_request = (fs == 1 || fs == 2 || fs == 4 || fs == 8) ? fs : 0;
   }
   k.slices = 1;
+  k.group = 1;
+  c->group_request = env_int("MTGPU_GROUP", 0);
   c->item_chunk = env_int("MTGPU_ITEM_CHUNK", 0);
   if (c->item_chunk < 0) c->item_chunk = 0;
   {
@@ -265,6 +268,23 @@ int choose_slices(const mtgpu_ctx *c, uint64_t n_records, uint32_t n_frames) {
   return (s == 2 || s == 4 || s == 8) ? s : 1;
 }
 
+// Frames per workgroup.  A workgroup should live for at least ~1 MB of records (tens of
+// microseconds): shorter ones are started more slowly than they finish, so only one per CU is
+// alive and nothing overlaps its zeroing / cluster test (phase timestamps, 1080p compact records:
+// 14-us workgroups, ~1 resident per CU).  Only for batches that fill the chip several times over.
+int choose_group(const mtgpu_ctx *c, uint64_t n_records, uint32_t n_frames, int rec_bytes, int slices) {
+  if (slices != 1 || n_frames == 0) return 1;
+  int g = c->group_request;
+  if (g <= 0) {
+    const uint64_t avg = n_records * (uint64_t)rec_bytes / n_frames;
+    const uint64_t cus = (uint64_t)(c->plan.cu_count > 0 ? c->plan.cu_count : 256);
+    g = 1;
+    while (g < 8 && avg * (uint64_t)(2 * g) <= (1ull << 20) && (uint64_t)n_frames >= cus * 8ull * (uint64_t)(2 * g)) g *= 2;
+  }
+  if (g > 64) g = 64;
+  return g < 1 ? 1 : g;
+}
+
 // Launches the scan on `st`; scratch (band centre counts, slice tiles + tickets) is allocated
 // and freed stream-ordered, so concurrent callers share nothing.
 int launch_scan_on(mtgpu_ctx *c, const void *d_mv, uint64_t n_records, const uint64_t *d_off,
@@ -284,6 +304,7 @@ int launch_scan_on(mtgpu_ctx *c, const void *d_mv, uint64_t n_records, const uin
   L.tickets = nullptr;
   L.k = c->k;
   L.k.slices = choose_slices(c, n_records, n_frames);
+  L.k.group = choose_group(c, n_records, n_frames, rec_bytes, L.k.slices);
   L.block = c->plan.block_threads;
   L.variant = c->variant;
   L.item_chunk = (unsigned long long)c->item_chunk;

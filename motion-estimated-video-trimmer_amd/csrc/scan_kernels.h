@@ -25,6 +25,7 @@ struct ScanK {
   int slices;              // workgroups per frame along the record array (1 = none; needs bands == 1)
   int cnt_words;           // LDS counter words per workgroup ((band_rows + 2) * gw fields, padded to 4)
   int mask_rows;           // chunk_rows + 2
+  int group;               // consecutive work items per workgroup (>= 1; > 1 only with slices == 1)
 };
 
 struct ScanLaunch {

@@ -277,16 +277,15 @@ __device__ __forceinline__ void vote(const MvFields m, const ScanK &k, int t0, i
   }
 }
 
+// One work item (a frame, or a frame slice) by one workgroup.
 template <int BLOCK, int UNROLL, int FB, int MODE, int VAR, int REC, bool SPILL>
-__global__ __launch_bounds__(BLOCK) void scan_frames_kernel(
+__device__ __forceinline__ void scan_item(
     const unsigned char *__restrict__ mv, unsigned long long n_records,
     const unsigned long long *__restrict__ frame_off, const unsigned char *__restrict__ has_sd,
-    unsigned int item0, unsigned int n_frames, ScanK k, unsigned char *__restrict__ flags,
-    unsigned int *spill_q, unsigned int *slice_ws, unsigned int *tickets) {
-  extern __shared__ __attribute__((aligned(16))) unsigned int lds[];
+    const unsigned int item, const ScanK &k, unsigned char *__restrict__ flags,
+    unsigned int *spill_q, unsigned int *slice_ws, unsigned int *tickets, unsigned int *lds) {
   typedef typename RawOf<REC>::type Raw;
   const int tid = threadIdx.x;
-  const unsigned int item = item0 + blockIdx.x;
   // item -> frame, or (frame, slice): bands and slices are never both > 1
   PT_DECL;
   const unsigned int f = SPILL ? item : item / (unsigned int)k.slices;
@@ -578,6 +577,28 @@ __global__ __launch_bounds__(BLOCK) void scan_frames_kernel(
   PT_FLUSH();
 }
 
+// Grid: one workgroup per k.group consecutive work items.  Small frames (a 1080p frame of compact
+// records is 261 KB = a 14-us workgroup) are grouped: the dispatcher starts ~19 workgroups per
+// microsecond, which keeps only ONE such workgroup per CU alive and leaves its zeroing and cluster
+// test un-overlapped; a workgroup that scans a few frames in a row lives long enough for 4 per CU.
+template <int BLOCK, int UNROLL, int FB, int MODE, int VAR, int REC, bool SPILL>
+__global__ __launch_bounds__(BLOCK) void scan_frames_kernel(
+    const unsigned char *__restrict__ mv, unsigned long long n_records,
+    const unsigned long long *__restrict__ frame_off, const unsigned char *__restrict__ has_sd,
+    unsigned int item0, unsigned int n_items, ScanK k, unsigned char *__restrict__ flags,
+    unsigned int *spill_q, unsigned int *slice_ws, unsigned int *tickets) {
+  extern __shared__ __attribute__((aligned(16))) unsigned int lds[];
+  const unsigned int first = item0 + blockIdx.x * (unsigned int)k.group;
+  for (int g = 0; g < k.group; ++g) {
+    const unsigned int item = first + (unsigned int)g;
+    if (item >= n_items) break;
+    // (no barrier between items: every LDS read of an item precedes its last barrier, and the
+    //  next item's writes start with its own zeroing)
+    scan_item<BLOCK, UNROLL, FB, MODE, VAR, REC, SPILL>(mv, n_records, frame_off, has_sd, item, k, flags, spill_q,
+                                                         slice_ws, tickets, lds);
+  }
+}
+
 // Calibration only: a pure streaming read shaped like the scan (one workgroup per contiguous
 // 1.25 MiB chunk, 512 threads, nt loads, 4 x 16 B in flight per lane, nothing else), folded into
 // a value that is (almost) never stored.  bench.py reports its rate on the scan's own record
@@ -629,11 +650,14 @@ static hipError_t launch_one(const ScanLaunch &L) {
     ready.fetch_or(bit, std::memory_order_release);
   }
   const unsigned long long items = (unsigned long long)L.n_frames * (unsigned long long)(SPILL ? 1 : L.k.slices);
-  const unsigned long long chunk = L.item_chunk ? L.item_chunk : (1ull << 30);   // grid.x stays < 2^31
-  for (unsigned long long i0 = 0; i0 < items; i0 += chunk) {
-    const unsigned int n = (unsigned int)((items - i0 < chunk) ? (items - i0) : chunk);
+  const unsigned long long group = (unsigned long long)(L.k.group > 0 ? L.k.group : 1);
+  const unsigned long long chunk = L.item_chunk ? L.item_chunk : (1ull << 30);   // workgroups per launch: grid.x stays < 2^31
+  for (unsigned long long i0 = 0; i0 < items; i0 += chunk * group) {
+    const unsigned long long left = items - i0;
+    const unsigned long long wgs = (left + group - 1) / group;
+    const unsigned int n = (unsigned int)(wgs < chunk ? wgs : chunk);
     hipLaunchKernelGGL(kern, dim3(n), dim3(BLOCK), L.lds_bytes, L.stream, L.mv, L.n_records,
-                       L.frame_off, L.has_sd, (unsigned int)i0, L.n_frames, L.k, L.flags, L.spill_q,
+                       L.frame_off, L.has_sd, (unsigned int)i0, (unsigned int)items, L.k, L.flags, L.spill_q,
                        L.slice_ws, L.tickets);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;

@@ -34,6 +34,8 @@ VARIANTS_BANDS = [("auto", dict()), ("tile160", dict(MTGPU_BAND_LDS_KB="160")), 
 VARIANTS_TILE = [("single", dict()), ("bands80", dict(MTGPU_MAX_TILE_KB="80")),
                  ("bands80/b512", dict(MTGPU_MAX_TILE_KB="80", MTGPU_FORCE_BLOCK="512")),
                  ("bands53", dict(MTGPU_MAX_TILE_KB="53", MTGPU_BAND_LDS_KB="53"))]
+VARIANTS_GROUP = [("auto", dict()), ("g1", dict(MTGPU_GROUP="1")), ("g2", dict(MTGPU_GROUP="2")), ("g4", dict(MTGPU_GROUP="4")),
+                  ("g8", dict(MTGPU_GROUP="8"))]
 VARIANTS = [("fb32", dict(MTGPU_FORCE_FB="32")), ("fb2", dict(MTGPU_FORCE_FB="2")),
             ("fb32/b512", dict(MTGPU_FORCE_FB="32", MTGPU_FORCE_BLOCK="512")),
             ("fb2/b512", dict(MTGPU_FORCE_FB="2", MTGPU_FORCE_BLOCK="512")),
@@ -69,12 +71,17 @@ def main():
         d_mv = torch.from_numpy(mv.view(np.uint8).copy()).to(dev).repeat(reps)[: int(off_big[-1]) * 40].contiguous()
         d_off = torch.from_numpy(off_big).to(dev)
         alg = 40 * int(off_big[-1]) + 9 * frames
+        compact = os.environ.get("AB_COMPACT") == "1"
+        if compact:                                 # the same batch as 8-byte compact records
+            rec = m.pack_records(mv)
+            d_mv = torch.from_numpy(rec.view(np.uint8).reshape(-1).copy()).to(dev).repeat(reps)[: int(off_big[-1]) * 8].contiguous()
+            alg = 8 * int(off_big[-1]) + 9 * frames
         scanners = []
         vset = {"fine": VARIANTS_FINE, "kernel": VARIANTS_KERNEL, "slices": VARIANTS_SLICES,
-                "bands": VARIANTS_BANDS, "tile": VARIANTS_TILE}.get(os.environ.get("AB_SET"), VARIANTS)
+                "bands": VARIANTS_BANDS, "tile": VARIANTS_TILE, "group": VARIANTS_GROUP}.get(os.environ.get("AB_SET"), VARIANTS)
         for name, env in vset:
             for k in ("MTGPU_FORCE_FB", "MTGPU_FORCE_BLOCK", "MTGPU_FORCE_CHUNK", "MTGPU_VARIANT", "MTGPU_FORCE_SLICES",
-                      "MTGPU_BAND_LDS_KB", "MTGPU_MAX_TILE_KB"):
+                      "MTGPU_BAND_LDS_KB", "MTGPU_MAX_TILE_KB", "MTGPU_GROUP"):
                 os.environ.pop(k, None)
             os.environ.update(env)
             try:
@@ -91,7 +98,7 @@ def main():
                 evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(rounds + 2)]
                 for e0, e1 in evs:
                     e0.record()
-                    s.check_frames_device(d_mv, d_off, None, fl)
+                    (s.check_frames_device_compact if compact else s.check_frames_device)(d_mv, d_off, None, fl)
                     e1.record()
                 torch.cuda.synchronize()
                 times.extend(e0.elapsed_time(e1) for e0, e1 in evs[2:])
@@ -100,7 +107,7 @@ def main():
             for name, s, plan, fl, times in scanners:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                s.check_frames_device(d_mv, d_off, None, fl)
+                (s.check_frames_device_compact if compact else s.check_frames_device)(d_mv, d_off, None, fl)
                 e1.record()
                 torch.cuda.synchronize()
                 if r >= 2:

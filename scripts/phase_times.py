@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Where a scan workgroup's time goes (developer tool).  Needs the instrumented build:
     make -C motion-estimated-video-trimmer_amd/csrc clean all EXTRA=-DMTGPU_PHASE_TIMES
-Usage: python scripts/phase_times.py [workload frames vec slices] ...   e.g.  4k_fine 1024 4 1"""
+Usage: python scripts/phase_times.py [workload frames vec slices] ...   e.g.  4k_fine 1024 4 1
+(a workload name with the suffix ":c" scans the batch as 8-byte compact records)"""
 import ctypes as C
 import os
 import sys
@@ -22,6 +23,8 @@ lib.mtgpu_debug_set_phase_times.argtypes = [C.c_void_p]
 args = sys.argv[1:] or ["4k_fine", "1024", "1", "1"]
 cases = [args[i:i + 4] for i in range(0, len(args), 4)]
 for wl, frames, vec, S in cases:
+    compact = wl.endswith(":c")
+    wl = wl[:-2] if compact else wl
     frames, vec, S = int(frames), int(vec), int(S)
     os.environ["AB_VEC"] = str(vec)
     w = bench.build_workload(wl, "code_defaults", frames, 30, 1000, dev)
@@ -34,14 +37,23 @@ for wl, frames, vec, S in cases:
     s.set_slices(S)
     plan = s.plan
     items = frames * max(S, 1)
+    if compact:
+        rec = m.pack_records(w["mv"])
+        d_rec = torch.from_numpy(rec.view(np.uint8).reshape(-1).copy()).to(dev).repeat(w["reps"])[: w["n_records"] * 8].contiguous()
+
+        def launch():
+            s.check_frames_device_compact(d_rec, w["d_off"], None, w["d_flags"])
+    else:
+        def launch():
+            s.check_frames_device(w["d_mv"], w["d_off"], None, w["d_flags"])
     for _ in range(3):
-        s.check_frames_device(w["d_mv"], w["d_off"], None, w["d_flags"])
+        launch()
     torch.cuda.synchronize()
     buf = torch.zeros(items * 8, dtype=torch.int64, device=dev)
     assert lib.mtgpu_debug_set_phase_times(buf.data_ptr()) == 0
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    s.check_frames_device(w["d_mv"], w["d_off"], None, w["d_flags"])
+    launch()
     e1.record()
     torch.cuda.synchronize()
     assert lib.mtgpu_debug_set_phase_times(None) == 0
@@ -51,7 +63,7 @@ for wl, frames, vec, S in cases:
 
     def st(x):
         return "mean %7.1f  p50 %7.1f  p95 %7.1f  max %7.1f" % (x.mean(), np.median(x), np.percentile(x, 95), x.max())
-    print(f"{wl} frames={frames} vec={vec} slices={S} plan: fb={plan['counter_bits']} block={plan['block_threads']} "
+    print(f"{wl}{' (compact records)' if compact else ''} frames={frames} vec={vec} slices={S} plan: fb={plan['counter_bits']} block={plan['block_threads']} "
           f"bands={plan['bands']} lds={plan['lds_bytes']}  kernel {e0.elapsed_time(e1):.3f} ms, {len(t)} workgroups with work")
     print("  start offset  :", st(t[:, 0] - t0), " concurrent ~%.0f" % ((t[:, 1] - t[:, 0]).sum() / (t[:, 1].max() - t0)))
     print("  lifetime      :", st(t[:, 1] - t[:, 0]))

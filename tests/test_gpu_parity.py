@@ -794,6 +794,30 @@ def test_scan_launch_chunking(gpu_scanner_factory):
         assert np.array_equal(got, want), (fb, slices, s.plan)
 
 
+def test_scan_frames_per_workgroup_grouping(gpu_scanner_factory, monkeypatch):
+    """Small frames are scanned several per workgroup (MTGPU_GROUP forces a count): the flags must
+    not depend on the grouping, including ragged tails, frames without side data inside a group,
+    banded plans and the compact layout."""
+    import torch
+    rng = np.random.RandomState(31)
+    cases = [(1920, 1080, dict(vectors_needed=1, clusters_needed=1), None),
+             (3840, 2160, dict(block_size=4, block_shift=2, vectors_needed=4), None)]       # row bands (spill queue)
+    for w, h, kw, fb in cases:
+        p = ob.params_from_config(w, h, **kw)
+        mv, off, sd = synth.random_frames(rng, 53, 1800, w, h, hot=0.4)
+        want = ob.scan_frames(p, mv, off, sd)
+        for g in (1, 2, 3, 7, 64):
+            monkeypatch.setenv("MTGPU_GROUP", str(g))
+            s = gpu_scanner_factory(m.ScanParams.from_config(w, h, **kw), force_fb=fb)
+            monkeypatch.delenv("MTGPU_GROUP")
+            assert np.array_equal(s.check_frames(m.FrameBatch(mv, off, None, sd)), want), (w, g)
+            rec = m.pack_records(mv)
+            got = s.check_frames_device_compact(torch.from_numpy(rec.view(np.uint8).reshape(-1).copy()).cuda(),
+                                                torch.from_numpy(off.astype(np.int64)).cuda(),
+                                                torch.from_numpy(sd).cuda()).cpu().numpy()
+            assert np.array_equal(got, want), (w, g, "compact")
+
+
 def test_plain_c_example(tmp_path):
     """examples/scan_example.c: the ABI consumed from plain C (gcc), end to end on the GPU."""
     import os
