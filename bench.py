@@ -289,6 +289,11 @@ def other_workloads(dev, distinct):
 # ---------------------------------------------------------------------------- one rank
 
 def run_rank(a):
+    # stdout carries exactly ONE line, the JSON: anything libraries print on fd 1 (gloo's connection
+    # notes, RCCL info lines) goes to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -465,7 +470,8 @@ def run_rank(a):
             "host_fed": host,
             "motion_frames_in_batch": int(flags_host.sum()),
         }
-        print(json.dumps(line), flush=True)
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+    os.close(json_fd)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
