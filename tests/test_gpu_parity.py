@@ -831,3 +831,20 @@ def test_plain_c_example(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "motion frames 30, segments 1, do_cut 1" in out.stdout and "[0.500, 2.467]" in out.stdout
+
+
+def test_plain_c_pipe_example(tmp_path):
+    """examples/pipe_example.c: the decoder-thread usage of the pinned pipe (acquire / add_frame /
+    submit / collect / release with back-pressure) from plain C, end to end on the GPU."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.dirname(m.LIB_PATH)
+    exe = str(tmp_path / "pipe_example")
+    subprocess.check_call(["gcc", "-std=c11", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "examples", "pipe_example.c"), "-o", exe, "-L" + pkg, "-lmtgpu",
+                           "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "motion frames 58, segments 2, do_cut 1" in out.stdout
+    assert "[1.533, 3.467]" in out.stdout and "[7.533, 9.467]" in out.stdout
