@@ -69,17 +69,19 @@ class LibavSource : public FrameSource {
     if (!codec) fail("no decoder");
     dec_ = avcodec_alloc_context3(codec);
     if (!dec_ || avcodec_parameters_to_context(dec_, par) < 0) fail("decoder context");
-    dec_->skip_loop_filter = AVDISCARD_ALL;     // pixels are never looked at
-    dec_->skip_idct = AVDISCARD_ALL;
-    dec_->skip_frame = AVDISCARD_BIDIR;         // B-frames never reach the scan
-    dec_->flags2 |= AV_CODEC_FLAG2_FAST;
-    dec_->flags |= AV_CODEC_FLAG_GRAY;
-    dec_->thread_count = 1;                     // parallelism is per chunk, not per frame
-    dec_->thread_type = FF_THREAD_SLICE;
+    // Decoder configuration through AVOptions (one table, applied by avcodec_open2): the scan needs
+    // the exported motion vectors only, never pixels — no in-loop filter, no IDCT, no B-frames
+    // (they never reach check_frame, src/motion_scanner.cpp:154), luma-only fast paths, and one
+    // decoding thread per scanner because parallelism is per chunk (src/pipeline.cpp:186-197).
+    static const char *const kDecoderOptions[][2] = {
+        {"flags2", "+export_mvs+fast"}, {"flags", "+gray"},       {"skip_frame", "bidir"},
+        {"skip_idct", "all"},           {"skip_loop_filter", "all"}, {"threads", "1"},
+        {"thread_type", "slice"},
+    };
     AVDictionary *opts = nullptr;
-    av_dict_set(&opts, "flags2", "+export_mvs", 0);
+    for (const auto &kv : kDecoderOptions) av_dict_set(&opts, kv[0], kv[1], 0);
     const int rc = avcodec_open2(dec_, codec, &opts);
-    av_dict_free(&opts);
+    av_dict_free(&opts);       // entries the decoder did not consume are dropped with the dictionary
     if (rc < 0) fail("avcodec_open2");
   }
   ~LibavSource() override { close(); }
