@@ -432,6 +432,36 @@ def test_compact_records_match_aos_everywhere(gpu_scanner_factory):
         assert np.array_equal(scan_compact(s, mv, off, None), ob.scan_frames(p, mv, off, None))
 
 
+def test_compact_records_any_8_byte_alignment(gpu_scanner_factory):
+    """The compact array may start at any 8-byte boundary (the kernel loads record PAIRS with
+    16-byte loads from the first 16-byte aligned record on and handles the odd ends separately);
+    frames with 0, 1, 2 and 3 records; an odd base is rejected."""
+    import torch
+    rng = np.random.RandomState(123)
+    p = ob.params_from_config(1920, 1080, vectors_needed=1, clusters_needed=1)
+    s = gpu_scanner_factory(m.ScanParams.from_config(1920, 1080, vectors_needed=1, clusters_needed=1))
+    mv, off, sd = synth.random_frames(rng, 40, 3000, 1920, 1080, hot=0.5)
+    tiny = [mv[:0], mv[5:6], mv[10:12], mv[20:23]]                 # 0, 1, 2, 3 records
+    b = m.FrameBatch.from_frames([mv[int(off[i]):int(off[i + 1])] if sd[i] else None for i in range(40)] + tiny)
+    want = ob.scan_frames(p, b.mv, b.frame_off, b.has_sd)
+    rec = torch.from_numpy(m.pack_records(b.mv).view(np.uint8).reshape(-1).copy())
+    d_off = torch.from_numpy(b.frame_off.astype(np.int64)).cuda()
+    d_sd = torch.from_numpy(b.has_sd).cuda()
+    for shift in (0, 8, 16, 24, 40):
+        buf = torch.zeros(rec.numel() + 64, dtype=torch.uint8, device="cuda")
+        view = buf[shift:shift + rec.numel()]
+        view.copy_(rec)
+        assert view.data_ptr() % 16 == shift % 16
+        for slices in (1, 2):
+            s.set_slices(slices)
+            got = s.check_frames_device_compact(view, d_off, d_sd).cpu().numpy()
+            assert np.array_equal(got, want), (shift, slices)
+    s.set_slices(0)
+    with pytest.raises(m.MtgpuError) as ei:
+        s.check_frames_device_compact(torch.zeros(rec.numel() + 8, dtype=torch.uint8, device="cuda")[4:4 + rec.numel()], d_off, d_sd)
+    assert ei.value.code == 1
+
+
 @pytest.mark.parametrize("layout", [m.LAYOUT_COMPACT8, m.LAYOUT_AOS40, m.LAYOUT_COMPACT8 | m.LAYOUT_ZERO_COPY,
                                     m.LAYOUT_AOS40 | m.LAYOUT_ZERO_COPY])
 def test_scan_pipe_layouts_and_oversize_frames(gpu_scanner_factory, layout):
