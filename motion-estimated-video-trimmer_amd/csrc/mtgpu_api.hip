@@ -79,6 +79,7 @@ struct mtgpu_ctx {
   int item_chunk = 0;    // MTGPU_ITEM_CHUNK (tests): work items per kernel launch, 0 = 2^30
   int lds_max = 0;       // device limit of LDS per workgroup
   int group_request = 0; // MTGPU_GROUP: frames per workgroup, 0 = automatic
+  hipMemPool_t pool = nullptr;   // private stream-ordered pool for launch scratch (freed blocks stay cached)
   uint64_t merge_large_min = 4096;   // timestamp lists at least this long take the multi-workgroup merge (MTGPU_MERGE_LARGE_MIN)
   std::mutex mu;         // guards the staging buffers below
   DevBuf d_mv, d_off, d_sd, d_flags, d_misc;
@@ -285,6 +286,15 @@ int choose_group(const mtgpu_ctx *c, uint64_t n_records, uint32_t n_frames, int 
   return g < 1 ? 1 : g;
 }
 
+// Stream-ordered scratch from the context's own pool.  The device's default pool hands freed
+// blocks back to the OS at the next synchronisation (release threshold 0), so the per-launch
+// scratch of banded plans (4 bytes per record: gigabytes for a 20 GB batch) would be re-mapped
+// after every host sync; the private pool keeps its blocks (release threshold = max).
+hipError_t scratch_alloc(mtgpu_ctx *c, void **p, size_t bytes, hipStream_t st) {
+  if (c->pool) return hipMallocFromPoolAsync(p, bytes, c->pool, st);
+  return hipMallocAsync(p, bytes, st);
+}
+
 // Launches the scan on `st`; scratch (band centre counts, slice tiles + tickets) is allocated
 // and freed stream-ordered, so concurrent callers share nothing.
 int launch_scan_on(mtgpu_ctx *c, const void *d_mv, uint64_t n_records, const uint64_t *d_off,
@@ -322,7 +332,7 @@ int launch_scan_on(mtgpu_ctx *c, const void *d_mv, uint64_t n_records, const uin
   if (L.k.slices > 1)
     bytes = sizeof(unsigned int) * ((size_t)n_frames * (size_t)L.k.slices * (size_t)L.k.cnt_words + (size_t)n_frames + 4);
   if (bytes) {
-    hipError_t e = hipMallocAsync(&scratch, bytes, st);
+    hipError_t e = scratch_alloc(c, &scratch, bytes, st);
     if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(scan scratch)");
     if (L.k.bands > 1) L.spill_q = static_cast<unsigned int *>(scratch);
     if (L.k.slices > 1) {
@@ -425,6 +435,21 @@ int mtgpu_create(const mt_scan_params *params, int device, mtgpu_ctx **out) {
   if (rc != MT_OK) { delete c; return rc; }
   e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete c; return hip_fail(e, "hipStreamCreate"); }
+  if (env_int("MTGPU_DEFAULT_POOL", 0) == 0) {
+    hipMemPoolProps props;
+    std::memset(&props, 0, sizeof props);
+    props.allocType = hipMemAllocationTypePinned;
+    props.handleTypes = hipMemHandleTypeNone;
+    props.location.type = hipMemLocationTypeDevice;
+    props.location.id = device;
+    if (hipMemPoolCreate(&c->pool, &props) == hipSuccess) {
+      uint64_t keep = ~0ull;
+      (void)hipMemPoolSetAttribute(c->pool, hipMemPoolAttrReleaseThreshold, &keep);
+    } else {
+      c->pool = nullptr;                 // fall back to the device's default pool
+      (void)hipGetLastError();
+    }
+  }
   *out = c;
   return MT_OK;
 }
@@ -433,6 +458,7 @@ void mtgpu_destroy(mtgpu_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+  if (c->pool) { (void)hipDeviceSynchronize(); (void)hipMemPoolDestroy(c->pool); }
   c->d_mv.release(); c->d_off.release(); c->d_sd.release(); c->d_flags.release(); c->d_misc.release();
   delete c;
 }
@@ -640,7 +666,7 @@ int mtgpu_merge_timestamps_device(mtgpu_ctx *c, const double *d_ts, uint64_t n, 
   hipStream_t st = static_cast<hipStream_t>(stream);
   const size_t wsb = merge_ts_ws_bytes(c, n) + 64;               // + the parameter block
   void *scratch = nullptr;
-  HIP_TRY(hipMallocAsync(&scratch, wsb, st));
+  HIP_TRY(scratch_alloc(c, &scratch, wsb, st));
   unsigned char *w = static_cast<unsigned char *>(scratch);
   int rc = MT_OK;
   hipError_t e = hipMemcpyAsync(w, mp, sizeof *mp, hipMemcpyHostToDevice, st);   // pageable source: staged at call time
