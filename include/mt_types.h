@@ -85,6 +85,11 @@ typedef struct mt_scan_params {
 /*
  * mt_segment — `TimeSegment{double start, end}` (include/motion_trim/types.hpp:56-59),
  * the record the cut executor consumes (include/motion_trim/ffmpeg_queue.hpp:32-38).
+ * Same size (16) and field offsets (0, 8) as the reference's struct, which is declared
+ * alignas(16); mt_segment deliberately asks only for the natural 8-byte alignment, so every
+ * TimeSegment array is a valid mt_segment array (INTEGRATION.md casts in that direction) and
+ * segment lists may sit at any 8-byte offset of a packed buffer (mtgpu_gather_segments).
+ * Checked against the compiled reference header in tests/test_reference_host.py.
  */
 typedef struct mt_segment {
   double start;

@@ -1,13 +1,54 @@
 """Environment-variable configuration, mirroring the reference's Config getters
 (include/motion_trim/config.hpp:28-125) for the values the scan path consumes.
 
-Same variable names, same code defaults, same parse types (stod / stoi / stof) and
-the same uint8 cast for VECTORS_NEEDED (config.hpp:75).  Unlike the reference's
-function-local statics the values are read at call time, so tests can vary them.
+Same variable names, same code defaults, same parse semantics and the same uint8 cast for
+VECTORS_NEEDED (config.hpp:75).  The reference parses with std::stod / std::stoi / std::stof
+(config.hpp:28-53), i.e. glibc strtod / strtol / strtof on the longest valid PREFIX ("7abc" -> 7,
+"0x10" -> 16.0 as a double but 0 as an int, leading whitespace skipped), std::invalid_argument when
+nothing converts and std::out_of_range on ERANGE (overflow AND underflow) or an int outside 32 bits.
+The getters below call the same libc functions, so every string gives the reference's value bit for
+bit (a float read through Python's float() would be rounded twice); the error cases raise ValueError
+(invalid_argument) and OverflowError (out_of_range).  Pinned by tests/golden/reference_host_vectors.json,
+which holds the answers of the reference's own config.hpp compiled and run (tests/test_reference_host.py).
+Unlike the reference's function-local statics the values are read at call time, so tests can vary them.
 """
+import ctypes
+import errno
 import os
 
-import numpy as np
+_libc = ctypes.CDLL(None, use_errno=True)
+_libc.strtod.restype = ctypes.c_double
+_libc.strtof.restype = ctypes.c_float
+_libc.strtol.restype = ctypes.c_long
+_libc.strtod.argtypes = _libc.strtof.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
+_libc.strtol.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int]
+
+
+def _strto(fn, text, what, *base):
+    buf = ctypes.create_string_buffer(os.fsencode(text))
+    end = ctypes.c_void_p()
+    ctypes.set_errno(0)
+    v = fn(buf, ctypes.byref(end), *base)
+    if (end.value or 0) == ctypes.addressof(buf):
+        raise ValueError(f"{what}: no conversion of {text!r}")           # std::invalid_argument
+    if ctypes.get_errno() == errno.ERANGE:
+        raise OverflowError(f"{what}: {text!r} out of range")            # std::out_of_range
+    return v
+
+
+def stod(text):
+    return _strto(_libc.strtod, text, "stod")
+
+
+def stof(text):
+    return _strto(_libc.strtof, text, "stof")
+
+
+def stoi(text):
+    v = _strto(_libc.strtol, text, "stoi", 10)
+    if not -2**31 <= v < 2**31:
+        raise OverflowError(f"stoi: {text!r} out of range")
+    return v
 
 
 def _env(name, default, conv):
@@ -15,48 +56,59 @@ def _env(name, default, conv):
     return conv(v) if v is not None else default
 
 
+_F32_0_05 = ctypes.c_float(0.05).value     # the literal 0.05f of config.hpp:87
+
+
 def mv_threshold_sq():      # config.hpp:56-59
-    return _env("MV_THRESHOLD_SQ", 16.0, float)
+    return _env("MV_THRESHOLD_SQ", 16.0, stod)
 
 
 def block_size():           # config.hpp:62-65
-    return _env("BLOCK_SIZE", 16, int)
+    return _env("BLOCK_SIZE", 16, stoi)
 
 
 def block_shift():          # config.hpp:68-71
-    return _env("BLOCK_SHIFT", 4, int)
+    return _env("BLOCK_SHIFT", 4, stoi)
 
 
 def vectors_needed():       # config.hpp:74-77  static_cast<uint8_t>(int)
-    return _env("VECTORS_NEEDED", 2, int) & 0xFF
+    return _env("VECTORS_NEEDED", 2, stoi) & 0xFF
 
 
 def clusters_needed():      # config.hpp:80-83
-    return _env("CLUSTERS_NEEDED", 2, int)
+    return _env("CLUSTERS_NEEDED", 2, stoi)
 
 
 def vertical_mask():        # config.hpp:86-89  (float32)
-    return float(np.float32(_env("VERTICAL_MASK", 0.05, float)))
+    return _env("VERTICAL_MASK", _F32_0_05, stof)
 
 
 def max_gap_sec():          # config.hpp:92-95
-    return _env("MAX_GAP_SEC", 5.0, float)
+    return _env("MAX_GAP_SEC", 5.0, stod)
 
 
 def padding_sec():          # config.hpp:98-101
-    return _env("PADDING_SEC", 0.5, float)
+    return _env("PADDING_SEC", 0.5, stod)
 
 
 def chunk_duration_sec():   # config.hpp:104-107
-    return _env("CHUNK_DURATION_SEC", 30.0, float)
+    return _env("CHUNK_DURATION_SEC", 30.0, stod)
 
 
 def target_fps():           # config.hpp:113-116
-    return _env("TARGET_FPS", 0.0, float)
+    return _env("TARGET_FPS", 0.0, stod)
 
 
 def min_savings_pct():      # config.hpp:122-125
-    return _env("MIN_SAVINGS_PCT", 5.0, float)
+    return _env("MIN_SAVINGS_PCT", 5.0, stod)
+
+
+def parallel_streams():     # config.hpp:138-141
+    return _env("PARALLEL_STREAMS", 0, stoi)
+
+
+def threads_per_stream():   # config.hpp:165-168
+    return _env("THREADS_PER_STREAM", 0, stoi)
 
 
 # The two parameter sets SURVEY.md §5 documents: code defaults and the shipped env file

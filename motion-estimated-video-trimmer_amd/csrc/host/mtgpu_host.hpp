@@ -59,6 +59,8 @@ struct Config {   // same variables, defaults and parse types as config.hpp:56-1
   static double chunk_duration_sec() { return env_d("CHUNK_DURATION_SEC", 30.0); }
   static double target_fps() { return env_d("TARGET_FPS", 0.0); }
   static double min_savings_pct() { return env_d("MIN_SAVINGS_PCT", 5.0); }
+  static int parallel_streams() { return env_i("PARALLEL_STREAMS", 0); }      // config.hpp:138-141, 0 = auto
+  static int threads_per_stream() { return env_i("THREADS_PER_STREAM", 0); }  // config.hpp:165-168, 0 = auto
   // not in the reference: pinned staging per batch of the host dispatcher, in MiB
   // (default: 4 for the compact layout — 16 workers x 3 batches stay inside the host's L3, so the DMA
   //  engine reads staging from cache — and 16 for the 40-byte layout)
@@ -522,6 +524,8 @@ class JobQueue {   // producer/consumer queue of finished scans, as ffmpeg_queue
     return true;
   }
   void finish() { { std::lock_guard<std::mutex> l(mu_); done_ = true; } cv_.notify_all(); }
+  bool empty() { std::lock_guard<std::mutex> l(mu_); return q_.empty(); }           // ffmpeg_queue.hpp:80-83
+  bool is_done() { std::lock_guard<std::mutex> l(mu_); return done_ && q_.empty(); } // ffmpeg_queue.hpp:75
 };
 
 // BatchProcessor's stream fan-out (batch_processor.cpp:81-157, 307-350) with GPUs in place of

@@ -1,0 +1,214 @@
+"""CPU tier: the host half of the scan path against answers of THE REFERENCE ITSELF.
+
+tests/golden/reference_host_vectors.json was recorded by running the reference's own config.hpp, types.hpp,
+src/task_queue.cpp and src/ffmpeg_queue.cpp (compiled where they lie under /root/reference by `make -C oracle
+ref`, driven by oracle/ref_host_probe.cpp; generator tests/golden/make_reference_host_vectors.py).  These files
+are the part of SURVEY.md §8's path that builds here without FFmpeg: env parsing and defaults of every scan /
+merge parameter (row a2's inputs), TaskQueue / ResultCollector (a7), FFmpegQueue / FFmpegJob (a10) and the
+TimeSegment layout the merge writes (a9/a10).  Replayed against
+
+  * mvtrim_amd.config              (Python mirror; same libc strto* calls as std::sto*)
+  * csrc/host/mtgpu_host.hpp       (C++ host layer, through tests/cpp/host_probe.cpp)
+  * include/mt_types.h             (mt_segment == TimeSegment)
+
+and, when oracle/_ref/ref_host_probe is present (build container, or the GPU box where the built binary
+travels), live against it on fresh random inputs.
+"""
+import json
+import os
+import random
+import subprocess
+
+import pytest
+
+import mvtrim_amd as m
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+PKG = os.path.dirname(m.LIB_PATH)
+VEC = json.load(open(os.path.join(HERE, "golden", "reference_host_vectors.json")))
+REF_PROBE = os.path.join(ROOT, "oracle", "_ref", "ref_host_probe")
+
+GETTERS = {
+    "mv_threshold_sq": m.config.mv_threshold_sq, "block_size": m.config.block_size,
+    "block_shift": m.config.block_shift, "vectors_needed": m.config.vectors_needed,
+    "clusters_needed": m.config.clusters_needed, "vertical_mask": m.config.vertical_mask,
+    "max_gap_sec": m.config.max_gap_sec, "padding_sec": m.config.padding_sec,
+    "chunk_duration_sec": m.config.chunk_duration_sec, "target_fps": m.config.target_fps,
+    "min_savings_pct": m.config.min_savings_pct, "parallel_streams": m.config.parallel_streams,
+    "threads_per_stream": m.config.threads_per_stream,
+}
+CONFIG_VARS = [k.upper() for k in GETTERS]
+
+
+@pytest.fixture(scope="module")
+def host_probe(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("probe") / "host_probe")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-I" + os.path.join(ROOT, "include"),
+                           "-I" + os.path.join(PKG, "csrc", "host"), os.path.join(HERE, "cpp", "host_probe.cpp"),
+                           "-o", exe, "-L" + PKG, "-lmtgpu", "-lpthread", "-Wl,-rpath," + PKG,
+                           "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def run(exe, args, env=None, stdin=None):
+    e = {"PATH": os.environ.get("PATH", ""), "LD_LIBRARY_PATH": os.environ.get("LD_LIBRARY_PATH", "")}
+    e.update(env or {})
+    out = subprocess.run([exe] + args, env=e, input=stdin, capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    return out.stdout.splitlines()
+
+
+def python_config_answers(env):
+    """The probe's `config` output, produced by mvtrim_amd.config under `env`."""
+    import struct
+    saved = {k: os.environ.pop(k, None) for k in CONFIG_VARS}
+    os.environ.update(env)
+    lines = []
+    try:
+        for name, fn in GETTERS.items():
+            try:
+                v = fn()
+            except ValueError:
+                lines.append(f"{name} error invalid_argument")
+                continue
+            except OverflowError:
+                lines.append(f"{name} error out_of_range")
+                continue
+            if name == "vertical_mask":
+                bits = struct.unpack("<I", struct.pack("<f", v))[0]
+                lines.append(f"{name} f32 {bits:#010x}")
+            elif isinstance(v, float):
+                bits = struct.unpack("<Q", struct.pack("<d", v))[0]
+                lines.append(f"{name} f64 {bits:#018x}")
+            else:
+                lines.append(f"{name} int {v}")
+    finally:
+        for k in CONFIG_VARS:
+            os.environ.pop(k, None)
+            if saved[k] is not None:
+                os.environ[k] = saved[k]
+    return lines
+
+
+def bits_only(lines):
+    """Drop the decimal rendering of float answers: '<name> f64 <dec> 0x<bits>' -> '<name> f64 0x<bits>'."""
+    out = []
+    for ln in lines:
+        p = ln.split()
+        out.append(" ".join([p[0], p[1], p[3]]) if p[1] in ("f64", "f32") else ln)
+    return out
+
+
+def test_fixture_is_reference_output():
+    assert "src/task_queue.cpp" in VEC["source"] and len(VEC["config"]) >= 80 and len(VEC["queue"]) >= 10
+    assert VEC["race"] == ["race values 6000 once 2000 of 2000 triples_intact 1"]
+
+
+@pytest.mark.parametrize("case", VEC["config"], ids=[c["name"] for c in VEC["config"]])
+def test_python_config_matches_reference(case):
+    assert python_config_answers(case["env"]) == bits_only(case["answers"])
+
+
+def test_cpp_host_config_matches_reference(host_probe):
+    for case in VEC["config"]:
+        assert run(host_probe, ["config"], case["env"]) == case["answers"], case["name"]
+
+
+def test_shipped_env_file_values():
+    """config/motion_trim.env as the reference reads it == the SHIPPED_ENV set bench and tests use."""
+    case = next(c for c in VEC["config"] if c["name"] == "shipped_env_file")
+    got = {ln.split()[0]: ln.split()[2] for ln in case["answers"]}
+    want = m.config.SHIPPED_ENV
+    assert float(got["mv_threshold_sq"]) == want["mv_threshold_sq"]
+    for k in ("block_size", "block_shift", "vectors_needed", "clusters_needed"):
+        assert int(got[k]) == want[k]
+    import numpy as np
+    assert np.float32(got["vertical_mask"]) == np.float32(want["vertical_mask"])
+    dflt = next(c for c in VEC["config"] if c["name"] == "code_defaults")
+    got = {ln.split()[0]: ln.split()[2] for ln in dflt["answers"]}
+    want = m.config.CODE_DEFAULTS
+    assert float(got["mv_threshold_sq"]) == want["mv_threshold_sq"]
+    for k in ("block_size", "block_shift", "vectors_needed", "clusters_needed"):
+        assert int(got[k]) == want[k]
+    assert np.float32(got["vertical_mask"]) == np.float32(want["vertical_mask"])
+
+
+def test_params_from_config_takes_reference_values():
+    """mtgpu_params_from_config over the reference's parsed values: u8 VECTORS_NEEDED, float32 mask."""
+    checked = 0
+    for case in VEC["config"]:
+        ans = {ln.split()[0]: ln.split() for ln in case["answers"]}
+        if any(v[1] == "error" for v in ans.values()):
+            continue
+        thr, mask = float(ans["mv_threshold_sq"][2]), float(ans["vertical_mask"][2])
+        bs, sh = int(ans["block_size"][2]), int(ans["block_shift"][2])
+        vn, cn = int(ans["vectors_needed"][2]), int(ans["clusters_needed"][2])
+        try:
+            p = m.ScanParams.from_config(1920, 1080, thr, bs, sh, vn, cn, mask)
+        except (m.MtgpuError, ValueError):
+            continue            # rejected parameter sets are covered by tests/test_host_logic.py
+        assert p.vectors_needed == vn and p.clusters_needed == cn and p.block_shift == sh
+        assert p.mv_threshold_sq == thr or thr != thr
+        checked += 1
+    assert checked >= 20
+
+
+def test_layout_matches_reference(host_probe):
+    ref = dict((ln.split()[0], ln.split()[1:]) for ln in VEC["layout"])
+    ours = dict((ln.split()[0], ln.split()[1:]) for ln in run(host_probe, ["layout"]))
+    assert ref["TimeSegment"] == "size 16 align 16 start 0 end 8".split()
+    # same size and offsets; mt_segment asks for LESS alignment (8), so a TimeSegment array is always a valid
+    # mt_segment array — the direction INTEGRATION.md casts in (include/mt_types.h)
+    assert ours["TimeSegment"] == "size 16 align 8 start 0 end 8".split()
+    assert ours["ScanTask"] == ref["ScanTask"][-6:]                       # same field order and offsets
+    assert m.SEGMENT_DTYPE.itemsize == 16
+    assert (m.SEGMENT_DTYPE.fields["start"][1], m.SEGMENT_DTYPE.fields["end"][1]) == (0, 8)
+
+
+@pytest.mark.parametrize("case", VEC["queue"], ids=[c["name"] for c in VEC["queue"]])
+def test_cpp_host_queues_match_reference(host_probe, case):
+    assert run(host_probe, ["queue"], stdin="\n".join(case["script"]) + "\n") == case["answers"]
+
+
+def test_cpp_host_race_matches_reference(host_probe):
+    assert run(host_probe, ["race", "2000", "8"]) == VEC["race"]
+
+
+def _random_env(rng):
+    pool = ["3", "4.75", "-2", " 9", "0x1F", "1e1", "12abc", "0.0625", "255", "256", ".5", "1e-3", "7."]
+    return {v: rng.choice(pool) for v in rng.sample(CONFIG_VARS, rng.randrange(1, len(CONFIG_VARS)))}
+
+
+@pytest.mark.skipif(not os.path.exists(REF_PROBE), reason="oracle/_ref/ref_host_probe not built (make -C oracle ref)")
+def test_live_against_reference_binary(host_probe):
+    rng = random.Random(7)
+    for _ in range(40):
+        env = _random_env(rng)
+        ref = run(REF_PROBE, ["config"], env)
+        assert run(host_probe, ["config"], env) == ref, env
+        assert python_config_answers(env) == bits_only(ref), env
+    for _ in range(10):
+        ops, tid = [], 0
+        for _ in range(200):
+            c = rng.random()
+            if c < 0.35:
+                ops.append(f"tpush {rng.uniform(0, 9e4)!r} {rng.uniform(0, 9e4)!r} {tid}")
+                tid += 1
+            elif c < 0.6:
+                ops.append("tpop")
+            elif c < 0.75:
+                n = rng.randrange(0, 6)
+                ops.append(("radd %d %s" % (n, " ".join(repr(rng.uniform(-1, 1e5)) for _ in range(n)))).strip())
+            elif c < 0.8:
+                ops.append("rextract")
+            elif c < 0.9:
+                n = rng.randrange(0, 4)
+                ops.append(("jpush %d %d %s" % (rng.randrange(64), n, " ".join(repr(rng.uniform(0, 1e4))
+                                                                             for _ in range(2 * n)))).strip())
+            else:
+                ops.append(rng.choice(["jpop", "jdone", "jempty", "tfinish", "jfinish"]))
+        ops += ["tfinish", "tpop", "jfinish", "jpop", "rextract"]
+        script = "\n".join(ops) + "\n"
+        assert run(host_probe, ["queue"], stdin=script) == run(REF_PROBE, ["queue"], stdin=script)
+    assert run(REF_PROBE, ["layout"]) == VEC["layout"]
