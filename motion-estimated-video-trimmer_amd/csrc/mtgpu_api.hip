@@ -79,6 +79,7 @@ struct mtgpu_ctx {
   int item_chunk = 0;    // MTGPU_ITEM_CHUNK (tests): work items per kernel launch, 0 = 2^30
   int lds_max = 0;       // device limit of LDS per workgroup
   int group_request = 0; // MTGPU_GROUP: frames per workgroup, 0 = automatic
+  int min_lds_kb = 0;    // MTGPU_MIN_LDS_KB: launch with at least this much LDS (caps workgroups per CU), 0 = automatic
   hipMemPool_t pool = nullptr;   // private stream-ordered pool for launch scratch (freed blocks stay cached)
   uint64_t merge_large_min = 4096;   // timestamp lists at least this long take the multi-workgroup merge (MTGPU_MERGE_LARGE_MIN)
   std::mutex mu;         // guards the staging buffers below
@@ -240,6 +241,7 @@ int make_plan(mtgpu_ctx *c, int lds_max, int cu_count) {
   k.slices = 1;
   k.group = 1;
   c->group_request = env_int("MTGPU_GROUP", 0);
+  c->min_lds_kb = env_int("MTGPU_MIN_LDS_KB", 0);
   c->item_chunk = env_int("MTGPU_ITEM_CHUNK", 0);
   if (c->item_chunk < 0) c->item_chunk = 0;
   {
@@ -325,6 +327,7 @@ int launch_scan_on(mtgpu_ctx *c, const void *d_mv, uint64_t n_records, const uin
     L.k.mask_rows = c->wide_chunk_rows + 2;
     L.lds_bytes = c->wide_lds_bytes;
   }
+  if (c->min_lds_kb > 0) L.lds_bytes = std::max(L.lds_bytes, std::min(c->min_lds_kb * 1024, c->lds_max));
   L.stream = st;
   void *scratch = nullptr;
   size_t bytes = 0;

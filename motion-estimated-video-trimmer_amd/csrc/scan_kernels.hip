@@ -515,16 +515,28 @@ __device__ __forceinline__ void scan_item(
           const int tw = t >> 2;
           const int j = tw / W, w = tw - j * W;
           const int g = c0 + q0r - 1 + j;                // grid row of this mask row
-          unsigned long long m = 0ull;
-          if (t < ntask && g >= t0 && g < t1) {          // outside the grid = inactive
+          const int ncell = min(64, k.gw - w * 64) - sub * 16;   // cells of this lane's quarter inside the grid
+          unsigned int q = 0u;                           // the quarter's 16 "active" bits
+          if (t < ntask && g >= t0 && g < t1 && ncell > 0) {     // outside the grid = inactive
             const unsigned int *row = cnt + (size_t)(g - t0) * k.gw + w * 64 + sub * 16;
-            const int ncell = min(64, k.gw - w * 64) - sub * 16;
+            const int last = min(ncell, 16) - 1;
+            // four LDS reads in flight per step; the loop is NOT fully unrolled on purpose: unrolled,
+            // the per-step lane constants (rotated column, its address, its 64-bit bit) of all 16
+            // steps were hoisted out of the task loop and held ~64 VGPRs for the whole kernel
+#pragma unroll 1
+            for (int c = 0; c < 16; c += 4) {
+              int cc[4];
+              unsigned int v[4];
 #pragma unroll
-            for (int c = 0; c < 16; ++c) {
-              const int cc = (c + rot) & 15;
-              if (cc < ncell && row[cc] >= k.active_min) m |= 1ull << (sub * 16 + cc);
+              for (int u = 0; u < 4; ++u) {
+                cc[u] = (c + u + rot) & 15;
+                v[u] = row[min(cc[u], last)];            // always inside the row: no branch around the read
+              }
+#pragma unroll
+              for (int u = 0; u < 4; ++u) q |= (unsigned int)(cc[u] <= last && v[u] >= k.active_min) << cc[u];
             }
           }
+          unsigned long long m = (unsigned long long)q << (sub * 16);
           m |= __shfl_xor(m, 1);
           m |= __shfl_xor(m, 2);
           if (t < ntask && sub == 0) mask[(size_t)j * W + w] = m;
