@@ -137,6 +137,8 @@ def build_workload(workload, params_name, frames, distinct, seed, dev):
     from mvtrim_amd import synth
     spec, (W, H, gridkw) = make_spec(workload, seed=seed)
     spec.events = synth.scripted_events(spec, distinct)
+    if os.environ.get("AB_PAN") == "1":      # developer scripts only: every MV above the threshold ("camera pan")
+        spec.events = [synth.Event(0, distinct, 0, 0, spec.cells_x, spec.cells_y, 9, 3)]
     mv, off, pts, sd = synth.gen_stream(spec, distinct)
     kw = dict(m.config.CODE_DEFAULTS if params_name == "code_defaults" else m.config.SHIPPED_ENV)
     kw.update(gridkw)
@@ -230,6 +232,11 @@ def host_fed_leg(spec, mv, off):
                 best = max(best, n * reps / max(j["scan_work_us"] * 1e-6, 1e-9))
             out[name + "_frames_per_s"] = best
     out["speedup"] = out["compact8_zero_copy_frames_per_s"] / out["aos40_copy_frames_per_s"]
+    # bytes that cross PCIe per frame: the staged records + offset + side-data byte in, one flag byte out
+    recs = float(np.mean([len(f) for f in frames]))
+    out["pcie_GBps"] = {"compact8_zero_copy": out["compact8_zero_copy_frames_per_s"] * (8 * recs + 10) / 1e9,
+                        "aos40_copy": out["aos40_copy_frames_per_s"] * (40 * recs + 10) / 1e9,
+                        "note": "PCIe gen5 x16: 64 GB/s raw, about 55 GB/s achievable one way"}
     return out
 
 

@@ -649,3 +649,82 @@ def test_merge_large_inputs_bit_exact(gpu_scanner_factory, n):
     # worst case for the in-order sum: every timestamp its own segment
     v = rng.permutation(np.arange(n, dtype=np.float64) * 7.0)
     _check_merge_equal(*s.merge_segments(v, mp, False), *ob.pool_and_merge(v, mp, False))
+
+
+# ------------------------------------------------------------------ parameter sets as the reference parses them
+
+def _varied_stream(rng, width, height, n_frames):
+    """8x8-block frames with jitter of 0-1 px and a few moving rectangles of assorted speed, size and
+    height, so that threshold, votes-per-cell, cluster count and vertical mask each flip some frames."""
+    bx, by = width // 8, height // 8
+    gx, gy = np.meshgrid(np.arange(bx), np.arange(by))
+    frames = []
+    for f in range(n_frames):
+        if f % 12 == 0:
+            frames.append(None)                          # I-frame: no side data
+            continue
+        dx = rng.integers(-1, 2, size=(by, bx))
+        dy = rng.integers(-1, 2, size=(by, bx)) * (rng.random((by, bx)) < 0.3)
+        for _ in range(int(rng.integers(0, 4))):
+            x0, y0 = int(rng.integers(0, bx - 2)), int(rng.integers(0, by - 2))
+            w, h = int(rng.integers(1, 9)), int(rng.integers(1, 7))
+            sp = int(rng.choice([2, 3, 4, 5, 9, 14]))
+            sel = (gx >= x0) & (gx < x0 + w) & (gy >= y0) & (gy < y0 + h)
+            dx = np.where(sel, sp, dx)
+            dy = np.where(sel, int(rng.integers(-2, 3)), dy)
+        keep = rng.random((by, bx)) < 0.9                # a few blocks carry no vector
+        rec = np.zeros(int(keep.sum()), dtype=m.MV_DTYPE)
+        rec["dst_x"] = (4 + 8 * gx)[keep]
+        rec["dst_y"] = (4 + 8 * gy)[keep]
+        rec["src_x"] = rec["dst_x"] - dx[keep]
+        rec["src_y"] = rec["dst_y"] - dy[keep]
+        rec["w"] = rec["h"] = 8
+        rec["source"] = -1
+        frames.append(rec)
+    b = m.FrameBatch.from_frames(frames)
+    return b.mv, b.frame_off, b.has_sd
+
+
+def test_scan_under_reference_parsed_configs(gpu_scanner_factory):
+    """Every environment of tests/golden/reference_host_vectors.json (answers of the reference's own
+    config.hpp, compiled and run: prefix parses, hex, the uint8 wrap of VECTORS_NEEDED, odd masks and
+    thresholds) becomes a parameter set through mtgpu_params_from_config and scans one 640x368 stream on
+    the HIP path, 40-byte and compact records, against the oracle under the same values."""
+    vec = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_host_vectors.json")))
+    mv, off, has_sd = _varied_stream(np.random.default_rng(31), 640, 368, 48)
+    seen, ran, some_motion = set(), 0, 0
+    for case in vec["config"]:
+        ans = {ln.split()[0]: ln.split() for ln in case["answers"]}
+        keys = ("mv_threshold_sq", "block_size", "block_shift", "vectors_needed", "clusters_needed", "vertical_mask")
+        if any(ans[k][1] == "error" for k in keys):
+            continue                                     # the reference terminates on these (uncaught std exception)
+        vals = (float(ans["mv_threshold_sq"][2]), int(ans["block_size"][2]), int(ans["block_shift"][2]),
+                int(ans["vectors_needed"][2]), int(ans["clusters_needed"][2]), float(ans["vertical_mask"][2]))
+        key = tuple(repr(v) for v in vals)
+        if key in seen:
+            continue
+        seen.add(key)
+        try:
+            po = ob.params_from_config(640, 368, *vals)
+        except Exception:
+            po = None
+        try:
+            p = m.ScanParams.from_config(640, 368, *vals)
+        except m.MtgpuError:
+            assert po is None, f"product rejects {case['name']} but the oracle accepts it"
+            continue
+        assert po is not None, f"oracle rejects {case['name']} but the product accepts it"
+        try:
+            want = ob.scan_frames(po, mv, off, has_sd)
+        except Exception:
+            with pytest.raises(m.MtgpuError):            # outside the defined domain for both (DESIGN.md §2 table)
+                gpu_scanner_factory(p)
+            continue
+        s = gpu_scanner_factory(p)
+        b = m.FrameBatch(mv, off, None, has_sd)
+        assert np.array_equal(s.check_frames(b), want), case["name"]
+        assert np.array_equal(scan_compact(s, mv, off, has_sd), want), case["name"]
+        ran += 1
+        some_motion += int(want.any())
+        s.close()
+    assert ran >= 25 and some_motion >= 5, (ran, some_motion)
