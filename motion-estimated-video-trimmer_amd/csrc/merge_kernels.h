@@ -11,7 +11,7 @@ namespace mtgpu {
 struct MergeLaunch {
   const unsigned char *flags;             // n_frames_total bytes or NULL (= every frame flagged)
   const double *pts;                      // n_frames_total
-  const unsigned long long *stream_off;   // n_streams + 1
+  const unsigned long long *stream_off;   // n_streams + 1; NULL (n_streams == 1): the one stream is [0, n_frames_total)
   unsigned long long n_frames_total;
   const mt_merge_params *mp;              // n_streams
   int job_semantics;
@@ -24,6 +24,9 @@ struct MergeLaunch {
 };
 
 hipError_t launch_merge(const MergeLaunch &L);
+
+// *d_dst = v on `stream` (v is captured at launch time).
+hipError_t launch_store_params(const mt_merge_params &v, mt_merge_params *d_dst, hipStream_t stream);
 
 // Multi-workgroup merge of ONE stream's pooled timestamps (any order, duplicates allowed), n >= 1:
 // device-wide sort (LDS tile sort + merge-path passes), then unique / gap merge / clamp / savings

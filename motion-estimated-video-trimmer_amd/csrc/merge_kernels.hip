@@ -93,7 +93,8 @@ __global__ __launch_bounds__(MB) void merge_streams_kernel(
   __shared__ Shared sh;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const unsigned int s = blockIdx.x;
-  unsigned long long a = stream_off[s], b = stream_off[s + 1];
+  // stream_off == NULL: ONE stream that spans [0, n_frames_total)
+  unsigned long long a = stream_off ? stream_off[s] : 0ull, b = stream_off ? stream_off[s + 1] : n_frames_total;
   b = b < n_frames_total ? b : n_frames_total;
   a = a < b ? a : b;
   const mt_merge_params mp = mp_arr[s];
@@ -513,8 +514,18 @@ hipError_t launch_merge_large(const double *d_ts, unsigned long long n, const mt
   return hipGetLastError();
 }
 
+// One parameter block by value -> device memory (kernel arguments are captured at launch, so the
+// caller's block may live on its stack; an async copy from pageable memory gives no such promise).
+__global__ void store_merge_params_kernel(mt_merge_params v, mt_merge_params *dst) { *dst = v; }
+
+hipError_t launch_store_params(const mt_merge_params &v, mt_merge_params *d_dst, hipStream_t st) {
+  hipLaunchKernelGGL(store_merge_params_kernel, dim3(1), dim3(1), 0, st, v, d_dst);
+  return hipGetLastError();
+}
+
 hipError_t launch_merge(const MergeLaunch &L) {
   if (L.n_streams == 0) return hipSuccess;
+  if (!L.stream_off && L.n_streams != 1) return hipErrorInvalidValue;
   hipLaunchKernelGGL(merge_streams_kernel, dim3(L.n_streams), dim3(MB), 0, L.stream, L.flags,
                      L.pts, L.stream_off, L.n_frames_total, L.mp, L.job_semantics, L.ts_ws, L.seg,
                      L.seg_cap, L.res);

@@ -96,6 +96,13 @@ unsigned long long threshold_to_int(double t) {
   return (unsigned long long)std::ceil(t);
 }
 
+// The synchronous entry points queue copies from / to CALLER memory: whatever way they return, the
+// stream has drained first, so the caller may free its buffers right away (also after an error).
+struct DrainOnExit {
+  hipStream_t st;
+  ~DrainOnExit() { (void)hipStreamSynchronize(st); }
+};
+
 int validate_params(const mt_scan_params *p) {
   if (!p) return fail(MT_ERR_INVALID, "params is NULL");
   if (p->grid_w < 1 || p->grid_h < 1 || p->grid_w > 32767 || p->grid_h > 32767)
@@ -570,6 +577,7 @@ int mtgpu_scan_frames(mtgpu_ctx *c, const mt_mv *mv, const uint64_t *frame_off,
   if (has_sd && (rc = c->d_sd.reserve(n_frames)) != MT_OK) return rc;
 
   hipStream_t st = c->stream;
+  DrainOnExit drain{st};
   if (n_records)
     HIP_TRY(hipMemcpyAsync(c->d_mv.p, mv + r_begin, (size_t)n_records * MT_MV_BYTES, hipMemcpyHostToDevice, st));
   // offsets are rebased to the copied window on the device side by passing a shifted base
@@ -634,12 +642,10 @@ int merge_ts_on(mtgpu_ctx *c, const double *d_ts, uint64_t n, const mt_merge_par
     return MT_OK;
   }
   unsigned char *w = static_cast<unsigned char *>(ws);
-  const uint64_t off[2] = {0, n};
-  HIP_TRY(hipMemcpyAsync(w, off, sizeof off, hipMemcpyHostToDevice, st));
   mtgpu::MergeLaunch L;
   L.flags = nullptr;
   L.pts = d_ts;
-  L.stream_off = reinterpret_cast<const unsigned long long *>(w);
+  L.stream_off = nullptr;                               // one stream: [0, n)
   L.n_frames_total = n;
   L.mp = d_mp;
   L.job_semantics = job_semantics;
@@ -672,8 +678,8 @@ int mtgpu_merge_timestamps_device(mtgpu_ctx *c, const double *d_ts, uint64_t n, 
   HIP_TRY(scratch_alloc(c, &scratch, wsb, st));
   unsigned char *w = static_cast<unsigned char *>(scratch);
   int rc = MT_OK;
-  hipError_t e = hipMemcpyAsync(w, mp, sizeof *mp, hipMemcpyHostToDevice, st);   // pageable source: staged at call time
-  if (e != hipSuccess) rc = hip_fail(e, "H2D merge params");
+  hipError_t e = mtgpu::launch_store_params(*mp, reinterpret_cast<mt_merge_params *>(w), st);   // by value: captured now
+  if (e != hipSuccess) rc = hip_fail(e, "merge params launch");
   if (rc == MT_OK)
     rc = merge_ts_on(c, d_ts, n, reinterpret_cast<const mt_merge_params *>(w), job_semantics, w + 64, d_seg, seg_cap,
                      d_res, st);
@@ -703,6 +709,7 @@ int mtgpu_merge_segments(mtgpu_ctx *c, const double *ts, uint64_t n, const mt_me
   if (rc != MT_OK) return rc;
   unsigned char *d = static_cast<unsigned char *>(c->d_misc.p);
   hipStream_t st = c->stream;
+  DrainOnExit drain{st};
   if (n) HIP_TRY(hipMemcpyAsync(d + o_pts, ts, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemcpyAsync(d + o_mp, mp, sizeof *mp, hipMemcpyHostToDevice, st));
   rc = merge_ts_on(c, reinterpret_cast<const double *>(d + o_pts), n, reinterpret_cast<const mt_merge_params *>(d + o_mp),

@@ -96,24 +96,27 @@ void free_batch(mtgpu_batch *b) {
   } while (0)
 
 // (Re)allocate the staging block of a batch for `records` records; the batch must be idle and
-// empty (cap_frames is already set).
+// empty (cap_frames is already set).  The new blocks are allocated BEFORE the old ones are let go:
+// when that fails the batch keeps its previous staging and capacity, so it stays usable.
 int alloc_records(mtgpu_batch *b, uint64_t records) {
   int rc = MT_OK;
-  unsigned char *dev_view = nullptr;
-  if (b->h_stage) (void)hipHostFree(b->h_stage);
-  if (b->d_stage) (void)hipFree(b->d_stage);
-  b->h_stage = nullptr; b->d_stage = nullptr; b->cap_records = 0;
+  unsigned char *h_new = nullptr, *d_new = nullptr, *dev_view = nullptr;
   const size_t nf = (size_t)b->cap_frames;
-  b->hdr_bytes = (sizeof(uint64_t) * (nf + 1) + (nf + 1) + 63u) & ~(size_t)63u;
-  const size_t bytes = b->hdr_bytes + (size_t)records * (size_t)b->rec_bytes + 64;
-  PIPE_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_stage), bytes, hipHostMallocDefault));
+  const size_t hdr = (sizeof(uint64_t) * (nf + 1) + (nf + 1) + 63u) & ~(size_t)63u;
+  const size_t bytes = hdr + (size_t)records * (size_t)b->rec_bytes + 64;
+  PIPE_TRY(hipHostMalloc(reinterpret_cast<void **>(&h_new), bytes, hipHostMallocDefault));
   if (b->zero_copy) {
     // no device mirror: the kernel reads the pinned block through its device-visible address
-    PIPE_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&dev_view), b->h_stage, 0));
+    PIPE_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&dev_view), h_new, 0));
   } else {
-    PIPE_TRY(hipMalloc(reinterpret_cast<void **>(&b->d_stage), bytes));
-    dev_view = b->d_stage;
+    PIPE_TRY(hipMalloc(reinterpret_cast<void **>(&d_new), bytes));
+    dev_view = d_new;
   }
+  if (b->h_stage) (void)hipHostFree(b->h_stage);
+  if (b->d_stage) (void)hipFree(b->d_stage);
+  b->h_stage = h_new;
+  b->d_stage = d_new;
+  b->hdr_bytes = hdr;
   b->h_off = reinterpret_cast<uint64_t *>(b->h_stage);
   b->h_sd = b->h_stage + sizeof(uint64_t) * (nf + 1);
   b->h_mv = b->h_stage + b->hdr_bytes;
@@ -124,8 +127,8 @@ int alloc_records(mtgpu_batch *b, uint64_t records) {
   b->cap_records = records;
   return MT_OK;
 bad:
-  if (b->h_stage) (void)hipHostFree(b->h_stage);
-  b->h_stage = nullptr; b->h_mv = nullptr; b->h_off = nullptr; b->h_sd = nullptr;
+  if (h_new) (void)hipHostFree(h_new);
+  if (d_new) (void)hipFree(d_new);
   return rc;
 }
 
