@@ -269,7 +269,11 @@ class GpuMotionScanner {   // public shape of MotionScanner (motion_scanner.hpp:
     const auto w0 = std::chrono::high_resolution_clock::now();
     const bool got = ok(mtgpu_pipe_collect(pipe_, &b, &flags, &pts, nullptr, &n));
     wait_us_ += since(w0);
-    if (!got) return false;
+    if (!got) {
+      // a failed collect still hands the batch out (include/mtgpu.h): give it back, keep the first error
+      if (b) { const std::string first = err_; --inflight_; (void)mtgpu_pipe_release(pipe_, b); err_ = first; }
+      return false;
+    }
     for (uint32_t i = 0; i < n; ++i)
       if (flags[i]) ts.push_back(pts[i]);                    // :382-383
     --inflight_;

@@ -387,8 +387,14 @@ class ScanPipe:
 
     def _collect_one(self):
         b, fl, pts, tags, n = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint32()
-        check(self._lib.mtgpu_pipe_collect(self._pipe, C.byref(b), C.byref(fl), C.byref(pts), C.byref(tags),
-                                           C.byref(n)))
+        rc = self._lib.mtgpu_pipe_collect(self._pipe, C.byref(b), C.byref(fl), C.byref(pts), C.byref(tags),
+                                          C.byref(n))
+        if rc != _abi.MT_OK:
+            msg = self._lib.mtgpu_last_error().decode("utf-8", "replace")
+            if b.value:                         # a failed collect still hands the batch out: give it back
+                self._lib.mtgpu_pipe_release(self._pipe, b)
+                self._inflight -= 1
+            raise _abi.MtgpuError(rc, msg)
         k = n.value
         if k:
             f = np.ctypeslib.as_array(C.cast(fl, C.POINTER(C.c_uint8)), (k,)).copy()
