@@ -278,10 +278,13 @@ int choose_slices(const mtgpu_ctx *c, uint64_t n_records, uint32_t n_frames) {
   return (s == 2 || s == 4 || s == 8) ? s : 1;
 }
 
-// Frames per workgroup.  A workgroup should live for at least ~1 MB of records (tens of
-// microseconds): shorter ones are started more slowly than they finish, so only one per CU is
-// alive and nothing overlaps its zeroing / cluster test (phase timestamps, 1080p compact records:
-// 14-us workgroups, ~1 resident per CU).  Only for batches that fill the chip several times over.
+// Frames per workgroup.  Very short workgroups are started more slowly than they finish (the
+// dispatcher starts ~19 per microsecond), so few are alive per CU and nothing overlaps their
+// zeroing / cluster test: frames below ~128 KB are scanned two or more per workgroup.  Measured
+// after the 32-bit kernels dropped to 58-61 VGPRs (four workgroups per CU): 65 KB frames (1080p,
+// one compact record per cell) +5 % with 2-4 per workgroup; 252 KB and 326 KB frames are 2-3 %
+// FASTER one per workgroup (the earlier 1 MB target dated from two workgroups per CU).
+// Only for batches that fill the chip several times over.
 int choose_group(const mtgpu_ctx *c, uint64_t n_records, uint32_t n_frames, int rec_bytes, int slices) {
   if (slices != 1 || n_frames == 0) return 1;
   int g = c->group_request;
@@ -289,7 +292,7 @@ int choose_group(const mtgpu_ctx *c, uint64_t n_records, uint32_t n_frames, int 
     const uint64_t avg = n_records * (uint64_t)rec_bytes / n_frames;
     const uint64_t cus = (uint64_t)(c->plan.cu_count > 0 ? c->plan.cu_count : 256);
     g = 1;
-    while (g < 8 && avg * (uint64_t)(2 * g) <= (1ull << 20) && (uint64_t)n_frames >= cus * 8ull * (uint64_t)(2 * g)) g *= 2;
+    while (g < 8 && avg * (uint64_t)(2 * g) <= (1ull << 18) && (uint64_t)n_frames >= cus * 8ull * (uint64_t)(2 * g)) g *= 2;
   }
   if (g > 64) g = 64;
   return g < 1 ? 1 : g;

@@ -589,10 +589,10 @@ __device__ __forceinline__ void scan_item(
   PT_FLUSH();
 }
 
-// Grid: one workgroup per k.group consecutive work items.  Small frames (a 1080p frame of compact
-// records is 261 KB = a 14-us workgroup) are grouped: the dispatcher starts ~19 workgroups per
-// microsecond, which keeps only ONE such workgroup per CU alive and leaves its zeroing and cluster
-// test un-overlapped; a workgroup that scans a few frames in a row lives long enough for 4 per CU.
+// Grid: one workgroup per k.group consecutive work items.  Small frames (below ~128 KB: a few
+// microseconds of work) are grouped: the dispatcher starts ~19 workgroups per microsecond, which
+// keeps too few such workgroups alive per CU to overlap their zeroing and cluster tests; a
+// workgroup that scans a few frames in a row lives long enough (choose_group, mtgpu_api.hip).
 template <int BLOCK, int UNROLL, int FB, int MODE, int VAR, int REC, bool SPILL>
 __global__ __launch_bounds__(BLOCK) void scan_frames_kernel(
     const unsigned char *__restrict__ mv, unsigned long long n_records,
