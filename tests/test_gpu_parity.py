@@ -848,3 +848,57 @@ def test_plain_c_pipe_example(tmp_path):
     assert out.returncode == 0, out.stdout + out.stderr
     assert "motion frames 58, segments 2, do_cut 1" in out.stdout
     assert "[1.533, 3.467]" in out.stdout and "[7.533, 9.467]" in out.stdout
+
+
+def test_one_context_entered_from_many_threads(gpu_scanner_factory):
+    """include/mtgpu.h promises that every entry point may be called concurrently on ONE context (the
+    reference enters its scanner code from N x S host threads, motion_scanner.hpp:8-13): eight threads
+    hammer the same context with the synchronous scan, the device-resident scan on their own streams
+    (40-byte and compact), a pipe each, and merges (small and multi-workgroup), all checked against the oracle."""
+    import threading
+    import torch
+    spec = synth.spec_1080p(seed=23, sub=1)
+    spec.events = synth.scripted_events(spec, 90)
+    p = ob.params_from_config(1920, 1080, vectors_needed=1)
+    s = gpu_scanner_factory(p)
+    mp = m.MergeParams(400.0, 1.0, 0.25, 5.0)
+    errors, lock = [], threading.Lock()
+
+    def worker(w):
+        try:
+            rng = np.random.default_rng(100 + w)
+            frames = [synth.gen_frame(spec, int(i)) for i in rng.integers(0, 90, size=40)]
+            b = m.FrameBatch.from_frames(frames)
+            want = ob.scan_frames(p, b.mv, b.frame_off, b.has_sd)
+            st = torch.cuda.Stream()
+            d_mv = torch.from_numpy(b.mv.view(np.uint8).reshape(-1).copy()).cuda()
+            d_rec = torch.from_numpy(m.pack_records(b.mv).view(np.uint8).reshape(-1).copy()).cuda()
+            d_off = torch.from_numpy(b.frame_off.astype(np.int64)).cuda()
+            d_sd = torch.from_numpy(b.has_sd).cuda()
+            torch.cuda.synchronize()
+            ts = np.sort(rng.uniform(0, 400, size=300 if w % 2 else 9000))
+            seg_want, res_want = ob.pool_and_merge(ts, mp, True)
+            for it in range(6):
+                assert np.array_equal(s.check_frames(b), want)
+                f1 = s.check_frames_device(d_mv, d_off, d_sd, stream=st.cuda_stream)
+                f2 = s.check_frames_device_compact(d_rec, d_off, d_sd, stream=st.cuda_stream)
+                pipe = m.ScanPipe(s, 8160 * 6, 16, 2, layout=(m.LAYOUT_COMPACT8 | m.LAYOUT_ZERO_COPY) if it % 2 else m.LAYOUT_AOS40)
+                for i, f in enumerate(frames):
+                    pipe.feed(f, float(i), tag=i)
+                out = pipe.drain()
+                pipe.close()
+                assert [fl for _, fl, _ in out] == want.tolist()
+                seg, res = s.merge_segments(rng.permutation(ts), mp, job_semantics=True)
+                assert np.array_equal(seg.view(np.uint64), seg_want.view(np.uint64)) and res["n_segments"] == res_want["n_segments"]
+                st.synchronize()
+                assert np.array_equal(f1.cpu().numpy(), want) and np.array_equal(f2.cpu().numpy(), want)
+        except BaseException as e:          # noqa: BLE001 - reported to the main thread
+            with lock:
+                errors.append((w, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(w,)) for w in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
