@@ -65,6 +65,7 @@ struct mtgpu_pipe {
   bool zero_copy = false;
   long inject_submit_fail = 0;   // MTGPU_INJECT_SUBMIT_FAIL=k (tests): the k-th submit fails after its copies were queued
   long submits = 0;
+  bool inject_grow_fail = false; // MTGPU_INJECT_GROW_FAIL=1 (tests): growing a batch for an oversize frame fails
   std::vector<mtgpu_batch *> bufs;
   std::deque<mtgpu_batch *> inflight;
   std::mutex mu;
@@ -98,13 +99,14 @@ void free_batch(mtgpu_batch *b) {
 // (Re)allocate the staging block of a batch for `records` records; the batch must be idle and
 // empty (cap_frames is already set).  The new blocks are allocated BEFORE the old ones are let go:
 // when that fails the batch keeps its previous staging and capacity, so it stays usable.
-int alloc_records(mtgpu_batch *b, uint64_t records) {
+int alloc_records(mtgpu_batch *b, uint64_t records, bool inject_failure = false) {
   int rc = MT_OK;
   unsigned char *h_new = nullptr, *d_new = nullptr, *dev_view = nullptr;
   const size_t nf = (size_t)b->cap_frames;
   const size_t hdr = (sizeof(uint64_t) * (nf + 1) + (nf + 1) + 63u) & ~(size_t)63u;
   const size_t bytes = hdr + (size_t)records * (size_t)b->rec_bytes + 64;
   PIPE_TRY(hipHostMalloc(reinterpret_cast<void **>(&h_new), bytes, hipHostMallocDefault));
+  if (inject_failure) { rc = fail(MT_ERR_NOMEM, "injected allocation failure (MTGPU_INJECT_GROW_FAIL)"); goto bad; }
   if (b->zero_copy) {
     // no device mirror: the kernel reads the pinned block through its device-visible address
     PIPE_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&dev_view), h_new, 0));
@@ -193,6 +195,7 @@ int mtgpu_pipe_create_layout(mtgpu_ctx *ctx, uint64_t max_records_per_batch, uin
   p->rec_bytes = (layout & MT_LAYOUT_AOS40) ? MT_MV_BYTES : MT_COMPACT_BYTES;
   p->zero_copy = (layout & MT_LAYOUT_ZERO_COPY) != 0;
   if (const char *v = std::getenv("MTGPU_INJECT_SUBMIT_FAIL")) p->inject_submit_fail = std::atol(v);
+  if (const char *v = std::getenv("MTGPU_INJECT_GROW_FAIL")) p->inject_grow_fail = std::atol(v) != 0;
   for (int i = 0; i < n_buffers; ++i) {
     mtgpu_batch *b = nullptr;
     int rc = alloc_batch(&b, max_records_per_batch, max_frames_per_batch, p->rec_bytes, p->zero_copy);
@@ -239,8 +242,8 @@ int mtgpu_batch_add_frame(mtgpu_batch *b, const void *mv_bytes, uint64_t n_bytes
     // buffers can be replaced.
     hipError_t e = hipSetDevice(mtgpu::ctx_device(b->owner->ctx));
     if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
-    int rc = alloc_records(b, n + n / 4);
-    if (rc != MT_OK) return rc;
+    int rc = alloc_records(b, n + n / 4, b->owner->inject_grow_fail);
+    if (rc != MT_OK) return rc;          // the batch keeps its previous staging and stays usable
   }
   if (n) {
     unsigned char *dst = b->h_mv + (size_t)b->n_records * (size_t)b->rec_bytes;

@@ -530,6 +530,44 @@ def test_pipe_submit_failure_leaves_batches_usable(gpu_scanner_factory, monkeypa
     pipe.close()
 
 
+@pytest.mark.parametrize("layout", ["compact_zc", "aos_copy"])
+def test_pipe_growth_failure_keeps_the_batch_usable(gpu_scanner_factory, monkeypatch, layout):
+    """A frame larger than a whole batch makes the pipe grow an empty batch; when that allocation fails
+    (MTGPU_INJECT_GROW_FAIL: the failure is raised inside the re-allocation, after the new pinned block
+    was obtained) the call reports MT_ERR_NOMEM and the batch keeps its previous staging: frames that
+    fit still go through with correct flags, and without the injection the same frame is accepted."""
+    spec = synth.spec_1080p(seed=29, sub=1)
+    spec.events = synth.scripted_events(spec, 40)
+    frames = [synth.gen_frame(spec, i) for i in range(40)]
+    big = np.concatenate([f for f in frames[1:6]])                # 5 frames' records as ONE frame: 40 800 records
+    p = ob.params_from_config(1920, 1080, vectors_needed=1)
+    s = gpu_scanner_factory(m.ScanParams.from_config(1920, 1080, vectors_needed=1))
+    b = m.FrameBatch.from_frames(frames)
+    want = ob.scan_frames(p, b.mv, b.frame_off, b.has_sd)
+    want_big = int(ob.check_frame(p, big))
+    lay = (m.LAYOUT_COMPACT8 | m.LAYOUT_ZERO_COPY) if layout == "compact_zc" else m.LAYOUT_AOS40
+    monkeypatch.setenv("MTGPU_INJECT_GROW_FAIL", "1")
+    pipe = m.ScanPipe(s, 8160 * 2, 4, 2, layout=lay)
+    monkeypatch.delenv("MTGPU_INJECT_GROW_FAIL")
+    for i in range(0, 10):
+        pipe.feed(frames[i], float(i), tag=i)
+    assert [fl for _, fl, _ in pipe.drain()] == want[:10].tolist()
+    with pytest.raises(m.MtgpuError) as e:
+        pipe.feed(big, 99.0, tag=99)                              # needs growth -> injected failure
+    assert e.value.code == m._abi.MT_ERR_NOMEM and "injected" in str(e.value)
+    for i in range(10, 40):                                       # the same batch, old staging intact
+        pipe.feed(frames[i], float(i), tag=i)
+    out = pipe.drain()
+    assert [t for _, _, t in out] == list(range(10, 40)) and [fl for _, fl, _ in out] == want[10:].tolist()
+    pipe.close()
+    pipe = m.ScanPipe(s, 8160 * 2, 4, 2, layout=lay)              # no injection: the batch grows
+    pipe.feed(frames[1], 0.0, tag=0)
+    pipe.feed(big, 1.0, tag=1)
+    pipe.feed(frames[2], 2.0, tag=2)
+    assert [fl for _, fl, _ in pipe.drain()] == [int(want[1]), want_big, int(want[2])]
+    pipe.close()
+
+
 def _fine_stream_file(tmp_path, n):
     spec = synth.StreamSpec(width=3840, height=2160, block=4, sub=1, fps=30.0, gop=12, seed=61, salt_p=1e-4)
     spec.events = [synth.Event(3, 9, 300, 200, 8, 6, 9, 3), synth.Event(20, 26, 500, 100, 5, 5, -7, 0)]
