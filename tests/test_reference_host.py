@@ -212,3 +212,19 @@ def test_live_against_reference_binary(host_probe):
         script = "\n".join(ops) + "\n"
         assert run(host_probe, ["queue"], stdin=script) == run(REF_PROBE, ["queue"], stdin=script)
     assert run(REF_PROBE, ["layout"]) == VEC["layout"]
+
+
+def test_cpp_host_queues_under_thread_sanitizer(tmp_path):
+    """TaskQueue / ResultCollector / JobQueue of the C++ host layer under -fsanitize=thread: 8 workers drain
+    2000 tasks (the reference's worker loop shape, pipeline.cpp:216-223) plus one scripted session; any data
+    race makes the sanitizer exit non-zero."""
+    exe = str(tmp_path / "host_probe_tsan")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-I" + os.path.join(ROOT, "include"),
+                           "-I" + os.path.join(PKG, "csrc", "host"), os.path.join(HERE, "cpp", "host_probe.cpp"),
+                           "-o", exe, "-L" + PKG, "-lmtgpu", "-lpthread", "-Wl,-rpath," + PKG,
+                           "-Wl,-rpath,/opt/rocm/lib"])
+    env = {"TSAN_OPTIONS": "halt_on_error=1 exitcode=66"}
+    for _ in range(3):
+        assert run(exe, ["race", "2000", "8"], env) == VEC["race"]
+    case = VEC["queue"][-1]
+    assert run(exe, ["queue"], env, stdin="\n".join(case["script"]) + "\n") == case["answers"]
