@@ -652,6 +652,12 @@ def test_merge_large_path_edge_sizes(gpu_scanner_factory, monkeypatch, job):
     same = np.full(5000, 7.25)
     for mp in mps:
         _check_merge_equal(*s.merge_segments(same, mp, job), *ob.pool_and_merge(same, mp, job))
+    # the edges of binary64 through the multi-workgroup path: denormals, 1e308, negatives, 2^53 neighbours
+    extreme = np.r_[5e-324, 1e-323, 2.2250738585072014e-308, -1e308, -3.5, -0.0, 1e308, 1.7976931348623157e308,
+                    2.0 ** 53, 2.0 ** 53 + 2, rng.rand(4200) * 1e4, np.arange(300) * 1e-310]
+    for mp in mps + [m.MergeParams(duration=1e308, max_gap_sec=1e-320, padding_sec=5e-324, min_savings_pct=0.0)]:
+        v = rng.permutation(extreme)
+        _check_merge_equal(*s.merge_segments(v, mp, job), *ob.pool_and_merge(v, mp, job))
     with pytest.raises(m.MtgpuError) as ei:
         s.merge_segments(np.r_[rng.rand(3000), float("nan"), rng.rand(3000)], mps[0], job)
     assert ei.value.code == 1
