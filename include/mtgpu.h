@@ -218,7 +218,8 @@ int mtgpu_pipe_acquire(mtgpu_pipe *pipe, mtgpu_batch **out);
  * `tag` is carried through untouched (e.g. a frame index).  MT_ERR_CAPACITY if the frame
  * does not fit the batch: submit this batch and add the frame to the next one.  A single frame
  * with more records than a whole batch is accepted (check_frame takes any count): an EMPTY
- * batch grows its staging to hold it. */
+ * batch grows its staging to hold it; if that allocation fails (MT_ERR_NOMEM / MT_ERR_DEVICE) the
+ * batch keeps its previous staging and stays usable for frames that fit. */
 int mtgpu_batch_add_frame(mtgpu_batch *batch, const void *mv_bytes, uint64_t n_bytes,
                           int has_side_data, double pts, uint64_t tag);
 uint32_t mtgpu_batch_frames(const mtgpu_batch *batch);
