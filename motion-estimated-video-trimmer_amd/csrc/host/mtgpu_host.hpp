@@ -413,6 +413,14 @@ struct PipelineResult {
 // `make_source` is called once per worker (+ once for the probe), like the per-thread
 // MotionScanner(file_buffer) of pipeline.cpp:197.
 // `pool` (optional, >= num_threads entries) lends each worker a GpuBackend that outlives this call.
+// Which GPU worker `worker` of a pipeline uses: pipelines (streams) start at device_base =
+// stream * threads_per_stream (process_batch), so concurrent streams and their workers spread
+// round-robin over the node's GPUs — the reference's stream -> CPU-set assignment
+// (batch_processor.cpp:102-110) with GPUs in place of CPU sets.
+inline int worker_device(int device_base, int worker, int n_devices) {
+  return n_devices > 0 ? (device_base + worker) % n_devices : 0;
+}
+
 template <class MakeSource>
 int run_scan_pipeline(MakeSource make_source, int num_threads, PipelineResult &out, int device_base = 0,
                       std::vector<std::unique_ptr<GpuBackend>> *pool = nullptr) {
@@ -452,7 +460,7 @@ int run_scan_pipeline(MakeSource make_source, int num_threads, PipelineResult &o
       const auto i0 = std::chrono::high_resolution_clock::now();
       sources[i] = make_source();
       GpuBackend *shared = (pool && (size_t)i < pool->size()) ? (*pool)[i].get() : nullptr;
-      scanners[i] = std::make_unique<GpuMotionScanner>(*sources[i], (device_base + i) % n_dev, shared);
+      scanners[i] = std::make_unique<GpuMotionScanner>(*sources[i], worker_device(device_base, i, n_dev), shared);
       if (!scanners[i]->initialize()) {                                  // :198-199 (here: reported)
         { std::lock_guard<std::mutex> l(err_mu); out.error = scanners[i]->error(); }
         arrive();

@@ -170,12 +170,23 @@ static int cmd_race(int n, int threads) {
   return once == n && triples_intact ? 0 : 1;
 }
 
+// stream s (of S), worker i (of T) -> device, on an N-GPU node: the table process_batch / run_scan_pipeline use
+static int cmd_devices(int streams, int threads, int n_dev) {
+  for (int s = 0; s < streams; ++s) {
+    std::printf("stream %d:", s);
+    for (int i = 0; i < threads; ++i) std::printf(" %d", h::worker_device(s * threads, i, n_dev));
+    std::printf("\n");
+  }
+  return 0;
+}
+
 int main(int argc, char **argv) {
   const std::string cmd = argc > 1 ? argv[1] : "";
   if (cmd == "config") return cmd_config();
   if (cmd == "layout") return cmd_layout();
   if (cmd == "queue") return cmd_queue();
   if (cmd == "race" && argc == 4) return cmd_race(std::atoi(argv[2]), std::atoi(argv[3]));
+  if (cmd == "devices" && argc == 5) return cmd_devices(std::atoi(argv[2]), std::atoi(argv[3]), std::atoi(argv[4]));
   std::fprintf(stderr, "usage: host_probe config|layout|queue|race N T\n");
   return 2;
 }

@@ -228,3 +228,18 @@ def test_cpp_host_queues_under_thread_sanitizer(tmp_path):
         assert run(exe, ["race", "2000", "8"], env) == VEC["race"]
     case = VEC["queue"][-1]
     assert run(exe, ["queue"], env, stdin="\n".join(case["script"]) + "\n") == case["answers"]
+
+
+def test_stream_to_gpu_assignment(host_probe):
+    """process_batch hands stream s the device base s * threads_per_stream; worker i then takes
+    (base + i) % n_devices.  BASELINE config 4 (64 streams, 8 GPUs): with one worker per stream every GPU
+    serves 8 streams; with 2 workers the pairs (0,1) (2,3) ... rotate; on one GPU everything is device 0."""
+    rows = [ln.split(":")[1].split() for ln in run(host_probe, ["devices", "64", "1", "8"])]
+    flat = [int(r[0]) for r in rows]
+    assert flat == [s % 8 for s in range(64)] and all(flat.count(d) == 8 for d in range(8))
+    rows = [[int(x) for x in ln.split(":")[1].split()] for ln in run(host_probe, ["devices", "8", "2", "8"])]
+    assert rows == [[(2 * s) % 8, (2 * s + 1) % 8] for s in range(8)]
+    rows = [[int(x) for x in ln.split(":")[1].split()] for ln in run(host_probe, ["devices", "3", "4", "1"])]
+    assert rows == [[0, 0, 0, 0]] * 3
+    rows = [[int(x) for x in ln.split(":")[1].split()] for ln in run(host_probe, ["devices", "2", "3", "4"])]
+    assert rows == [[0, 1, 2], [3, 0, 1]]
