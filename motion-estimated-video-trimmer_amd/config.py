@@ -10,7 +10,10 @@ The getters below call the same libc functions, so every string gives the refere
 bit (a float read through Python's float() would be rounded twice); the error cases raise ValueError
 (invalid_argument) and OverflowError (out_of_range).  Pinned by tests/golden/reference_host_vectors.json,
 which holds the answers of the reference's own config.hpp compiled and run (tests/test_reference_host.py).
-Unlike the reference's function-local statics the values are read at call time, so tests can vary them.
+Like the reference's function-local statics (config.hpp:56-59) every getter reads and parses its variable
+ONCE per process: a later change of the environment does not change the answer, and a value that failed to
+parse (the exception leaves the C++ static uninitialised) is parsed again on the next call.  `forget()`
+drops the memo (tests only; the reference has no such thing).
 """
 import ctypes
 import errno
@@ -51,9 +54,19 @@ def stoi(text):
     return v
 
 
+_memo = {}
+
+
+def forget():
+    """Tests only: read the environment afresh on the next call of each getter."""
+    _memo.clear()
+
+
 def _env(name, default, conv):
-    v = os.environ.get(name)
-    return conv(v) if v is not None else default
+    if name not in _memo:                       # an exception from conv leaves nothing behind: retried next call
+        v = os.environ.get(name)
+        _memo[name] = conv(v) if v is not None else default
+    return _memo[name]
 
 
 _F32_0_05 = ctypes.c_float(0.05).value     # the literal 0.05f of config.hpp:87
@@ -72,7 +85,7 @@ def block_shift():          # config.hpp:68-71
 
 
 def vectors_needed():       # config.hpp:74-77  static_cast<uint8_t>(int)
-    return _env("VECTORS_NEEDED", 2, stoi) & 0xFF
+    return _env("VECTORS_NEEDED", 2, lambda t: stoi(t) & 0xFF)
 
 
 def clusters_needed():      # config.hpp:80-83

@@ -48,34 +48,49 @@ struct Config {   // same variables, defaults and parse types as config.hpp:56-1
   static double env_d(const char *n, double d) { const char *v = std::getenv(n); return v ? std::stod(v) : d; }
   static int env_i(const char *n, int d) { const char *v = std::getenv(n); return v ? std::stoi(v) : d; }
   static float env_f(const char *n, float d) { const char *v = std::getenv(n); return v ? std::stof(v) : d; }
-  static double mv_threshold_sq() { return env_d("MV_THRESHOLD_SQ", 16.0); }
-  static int block_size() { return env_i("BLOCK_SIZE", 16); }
-  static int block_shift() { return env_i("BLOCK_SHIFT", 4); }
-  static int vectors_needed() { return static_cast<uint8_t>(env_i("VECTORS_NEEDED", 2)); }
-  static int clusters_needed() { return env_i("CLUSTERS_NEEDED", 2); }
-  static float vertical_mask() { return env_f("VERTICAL_MASK", 0.05f); }
-  static double max_gap_sec() { return env_d("MAX_GAP_SEC", 5.0); }
-  static double padding_sec() { return env_d("PADDING_SEC", 0.5); }
-  static double chunk_duration_sec() { return env_d("CHUNK_DURATION_SEC", 30.0); }
-  static double target_fps() { return env_d("TARGET_FPS", 0.0); }
-  static double min_savings_pct() { return env_d("MIN_SAVINGS_PCT", 5.0); }
-  static int parallel_streams() { return env_i("PARALLEL_STREAMS", 0); }      // config.hpp:138-141, 0 = auto
-  static int threads_per_stream() { return env_i("THREADS_PER_STREAM", 0); }  // config.hpp:165-168, 0 = auto
+  // Every getter reads and parses its variable ONCE per process, into a function-local static, exactly as
+  // config.hpp:56-59 does: later setenv() calls do not change the answer, initialisation is thread-safe
+  // (workers of N x S threads call these), and a value that does not parse throws from the initialiser —
+  // the static then stays uninitialised and the next call parses again (C++ [stmt.dcl]), as in the reference.
+  // Pinned by the reference's own config.hpp through the `memo` scripts of tests/test_reference_host.py.
+  static double mv_threshold_sq() { static double v = env_d("MV_THRESHOLD_SQ", 16.0); return v; }
+  static int block_size() { static int v = env_i("BLOCK_SIZE", 16); return v; }
+  static int block_shift() { static int v = env_i("BLOCK_SHIFT", 4); return v; }
+  static int vectors_needed() { static uint8_t v = static_cast<uint8_t>(env_i("VECTORS_NEEDED", 2)); return v; }
+  static int clusters_needed() { static int v = env_i("CLUSTERS_NEEDED", 2); return v; }
+  static float vertical_mask() { static float v = env_f("VERTICAL_MASK", 0.05f); return v; }
+  static double max_gap_sec() { static double v = env_d("MAX_GAP_SEC", 5.0); return v; }
+  static double padding_sec() { static double v = env_d("PADDING_SEC", 0.5); return v; }
+  static double chunk_duration_sec() { static double v = env_d("CHUNK_DURATION_SEC", 30.0); return v; }
+  static double target_fps() { static double v = env_d("TARGET_FPS", 0.0); return v; }
+  static double min_savings_pct() { static double v = env_d("MIN_SAVINGS_PCT", 5.0); return v; }
+  static int parallel_streams() { static int v = env_i("PARALLEL_STREAMS", 0); return v; }      // config.hpp:138-141, 0 = auto
+  static int threads_per_stream() { static int v = env_i("THREADS_PER_STREAM", 0); return v; }  // config.hpp:165-168, 0 = auto
+  // not in the reference: staging layout of the host dispatcher (include/mtgpu.h), "aos40" or "compact8"
+  // ("aos40", "compact8", either with the suffix "_zc" for zero-copy); read once like the rest
+  static int staging_layout() {
+    static int v = [] {
+      const char *e = std::getenv("MTGPU_STAGING");
+      const std::string s = e ? e : "compact8_zc";
+      int layout = s.rfind("aos40", 0) == 0 ? MT_LAYOUT_AOS40 : MT_LAYOUT_COMPACT8;
+      if (s.size() > 3 && s.compare(s.size() - 3, 3, "_zc") == 0) layout |= MT_LAYOUT_ZERO_COPY;
+      return layout;
+    }();
+    return v;
+  }
   // not in the reference: pinned staging per batch of the host dispatcher, in MiB
   // (default: 4 for the compact layout — 16 workers x 3 batches stay inside the host's L3, so the DMA
   //  engine reads staging from cache — and 16 for the 40-byte layout)
   static int batch_mib() {
-    const int v = env_i("MTGPU_BATCH_MB", (staging_layout() & MT_LAYOUT_AOS40) ? 16 : 4);
-    return v < 1 ? 1 : v;
+    static int v = std::max(1, env_i("MTGPU_BATCH_MB", (staging_layout() & MT_LAYOUT_AOS40) ? 16 : 4));
+    return v;
   }
-  // not in the reference: staging layout of the host dispatcher (include/mtgpu.h), "aos40" or "compact8"
-  // ("aos40", "compact8", either with the suffix "_zc" for zero-copy)
-  static int staging_layout() {
-    const char *v = std::getenv("MTGPU_STAGING");
-    const std::string s = v ? v : "compact8_zc";
-    int layout = s.rfind("aos40", 0) == 0 ? MT_LAYOUT_AOS40 : MT_LAYOUT_COMPACT8;
-    if (s.size() > 3 && s.compare(s.size() - 3, 3, "_zc") == 0) layout |= MT_LAYOUT_ZERO_COPY;
-    return layout;
+  // Parse everything the scan path reads, in the calling thread: a value that does not parse surfaces
+  // here as an exception (caught by run_scan_pipeline -> PipelineResult::error) instead of inside a worker.
+  static void load_all() {
+    (void)mv_threshold_sq(); (void)block_size(); (void)block_shift(); (void)vectors_needed(); (void)clusters_needed();
+    (void)vertical_mask(); (void)max_gap_sec(); (void)padding_sec(); (void)chunk_duration_sec(); (void)target_fps();
+    (void)min_savings_pct(); (void)staging_layout(); (void)batch_mib();
   }
 };
 
@@ -424,7 +439,10 @@ inline int worker_device(int device_base, int worker, int n_devices) {
 template <class MakeSource>
 int run_scan_pipeline(MakeSource make_source, int num_threads, PipelineResult &out, int device_base = 0,
                       std::vector<std::unique_ptr<GpuBackend>> *pool = nullptr) {
-  std::unique_ptr<FrameSource> probe = make_source();                    // pipeline.cpp:110-120
+  // every environment value is parsed here, once, in the calling thread (never first inside a worker)
+  try { Config::load_all(); } catch (const std::exception &e) { out.error = std::string("configuration: ") + e.what(); return 1; }
+  std::unique_ptr<FrameSource> probe;
+  try { probe = make_source(); } catch (const std::exception &e) { out.error = e.what(); return 1; }   // pipeline.cpp:110-120
   const double duration = probe->duration();
   const double chunk = Config::chunk_duration_sec();
   int n_dev = mtgpu_device_count();
@@ -457,31 +475,44 @@ int run_scan_pipeline(MakeSource make_source, int num_threads, PipelineResult &o
   };
   for (int i = 0; i < num_threads; ++i) {
     workers.emplace_back([&, i] {                                        // :186-235
-      const auto i0 = std::chrono::high_resolution_clock::now();
-      sources[i] = make_source();
-      GpuBackend *shared = (pool && (size_t)i < pool->size()) ? (*pool)[i].get() : nullptr;
-      scanners[i] = std::make_unique<GpuMotionScanner>(*sources[i], worker_device(device_base, i, n_dev), shared);
-      if (!scanners[i]->initialize()) {                                  // :198-199 (here: reported)
-        { std::lock_guard<std::mutex> l(err_mu); out.error = scanners[i]->error(); }
-        arrive();
-        return;
-      }
-      init_us += (long)std::chrono::duration_cast<std::chrono::microseconds>(
-                     std::chrono::high_resolution_clock::now() - i0).count();   // :195-206
-      arrive();
-      long s = 0, d = 0, a = 0;
-      ScanTask task;
-      while (tasks.pop(task)) {                                          // :216-223
-        auto r = scanners[i]->scan_range(task.start, task.end, s, d, a);
-        if (scanners[i]->failed()) {                                     // a failed range must fail the video
-          std::lock_guard<std::mutex> l(err_mu);
-          if (out.error.empty()) out.error = scanners[i]->error();
-          break;
+      // Nothing may escape a std::thread body (std::terminate): a throwing make_source() or a bad_alloc
+      // ends this worker with the video failed, and the start barrier still gets its arrival.
+      bool arrived = false;
+      auto fail_with = [&](const std::string &what) {
+        { std::lock_guard<std::mutex> l(err_mu); if (out.error.empty()) out.error = what; }
+        if (!arrived) { arrived = true; arrive(); }
+      };
+      try {
+        const auto i0 = std::chrono::high_resolution_clock::now();
+        sources[i] = make_source();
+        GpuBackend *shared = (pool && (size_t)i < pool->size()) ? (*pool)[i].get() : nullptr;
+        scanners[i] = std::make_unique<GpuMotionScanner>(*sources[i], worker_device(device_base, i, n_dev), shared);
+        if (!scanners[i]->initialize()) {                                // :198-199 (here: reported)
+          fail_with(scanners[i]->error());
+          return;
         }
-        if (!r.empty()) results.add(std::move(r));
+        init_us += (long)std::chrono::duration_cast<std::chrono::microseconds>(
+                       std::chrono::high_resolution_clock::now() - i0).count();   // :195-206
+        arrived = true;
+        arrive();
+        long s = 0, d = 0, a = 0;
+        ScanTask task;
+        while (tasks.pop(task)) {                                        // :216-223
+          auto r = scanners[i]->scan_range(task.start, task.end, s, d, a);
+          if (scanners[i]->failed()) {                                   // a failed range must fail the video
+            std::lock_guard<std::mutex> l(err_mu);
+            if (out.error.empty()) out.error = scanners[i]->error();
+            break;
+          }
+          if (!r.empty()) results.add(std::move(r));
+        }
+        seek_us += s; decode_us += d; analyze_us += a;
+        copy_us += scanners[i]->copy_us(); submit_us += scanners[i]->submit_us(); wait_us += scanners[i]->wait_us();
+      } catch (const std::exception &e) {
+        fail_with(std::string("worker ") + std::to_string(i) + ": " + e.what());
+      } catch (...) {
+        fail_with(std::string("worker ") + std::to_string(i) + ": unknown exception");
       }
-      seek_us += s; decode_us += d; analyze_us += a;
-      copy_us += scanners[i]->copy_us(); submit_us += scanners[i]->submit_us(); wait_us += scanners[i]->wait_us();
     });
   }
   tasks.finish();

@@ -10,11 +10,13 @@
 // tests/golden/make_reference_host_vectors.py can record the answers as fixtures.
 //
 //   ref_host_probe config            -> one line per Config getter, values as %.17g / raw bits
+//   ref_host_probe memo   < script   -> get / setenv / get again: the getters are function-local statics
 //   ref_host_probe layout            -> sizeof / alignof / offsets of TimeSegment, ScanTask
 //   ref_host_probe queue  < script   -> TaskQueue / ResultCollector / FFmpegQueue driven by a script
 //   ref_host_probe race N T          -> T threads drain N tasks; prints how often each id was popped
 #include <cstddef>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <exception>
 #include <iostream>
@@ -72,6 +74,39 @@ static int cmd_config() {
   show_d("min_savings_pct", [] { return mt::Config::min_savings_pct(); });
   show_i("parallel_streams", [] { return mt::Config::parallel_streams(); });
   show_i("threads_per_stream", [] { return mt::Config::threads_per_stream(); });
+  return 0;
+}
+
+// `memo`: the getters are function-local statics (config.hpp:56-59) — what a process sees when the environment
+// changes between two calls.  Script lines:  get <getter> | set NAME VALUE | unset NAME
+static int cmd_memo() {
+  std::string line;
+  while (std::getline(std::cin, line)) {
+    std::istringstream in(line);
+    std::string op, a, b;
+    if (!(in >> op) || op[0] == '#') continue;
+    in >> a;
+    std::getline(in, b);
+    if (!b.empty() && b[0] == ' ') b.erase(0, 1);
+    if (op == "set") { setenv(a.c_str(), b.c_str(), 1); std::printf("set ok\n"); }
+    else if (op == "unset") { unsetenv(a.c_str()); std::printf("unset ok\n"); }
+    else if (op == "get") {
+      if (a == "mv_threshold_sq") show_d("mv_threshold_sq", [] { return mt::Config::mv_threshold_sq(); });
+      else if (a == "block_size") show_i("block_size", [] { return mt::Config::block_size(); });
+      else if (a == "block_shift") show_i("block_shift", [] { return mt::Config::block_shift(); });
+      else if (a == "vectors_needed") show_i("vectors_needed", [] { return mt::Config::vectors_needed(); });
+      else if (a == "clusters_needed") show_i("clusters_needed", [] { return mt::Config::clusters_needed(); });
+      else if (a == "vertical_mask") show_f("vertical_mask", [] { return mt::Config::vertical_mask(); });
+      else if (a == "max_gap_sec") show_d("max_gap_sec", [] { return mt::Config::max_gap_sec(); });
+      else if (a == "padding_sec") show_d("padding_sec", [] { return mt::Config::padding_sec(); });
+      else if (a == "chunk_duration_sec") show_d("chunk_duration_sec", [] { return mt::Config::chunk_duration_sec(); });
+      else if (a == "target_fps") show_d("target_fps", [] { return mt::Config::target_fps(); });
+      else if (a == "min_savings_pct") show_d("min_savings_pct", [] { return mt::Config::min_savings_pct(); });
+      else if (a == "parallel_streams") show_i("parallel_streams", [] { return mt::Config::parallel_streams(); });
+      else if (a == "threads_per_stream") show_i("threads_per_stream", [] { return mt::Config::threads_per_stream(); });
+      else { std::printf("unknown getter %s\n", a.c_str()); return 2; }
+    } else { std::printf("unknown %s\n", op.c_str()); return 2; }
+  }
   return 0;
 }
 
@@ -198,6 +233,7 @@ static int cmd_race(int n, int threads) {
 int main(int argc, char **argv) {
   const std::string cmd = argc > 1 ? argv[1] : "";
   if (cmd == "config") return cmd_config();
+  if (cmd == "memo") return cmd_memo();
   if (cmd == "layout") return cmd_layout();
   if (cmd == "queue") return cmd_queue();
   if (cmd == "race" && argc == 4) return cmd_race(std::atoi(argv[2]), std::atoi(argv[3]));

@@ -27,10 +27,19 @@ int main(int argc, char **argv) {
   REQUIRE(Config::vectors_needed() == 2 && Config::clusters_needed() == 2 && Config::vertical_mask() == 0.05f);
   REQUIRE(Config::max_gap_sec() == 5.0 && Config::padding_sec() == 0.5 && Config::chunk_duration_sec() == 30.0);
   REQUIRE(Config::target_fps() == 0.0 && Config::min_savings_pct() == 5.0);
+  // read once per process (function-local statics, config.hpp:56-59): a later setenv changes nothing —
+  // the uint8 cast and every parse corner are pinned by tests/test_reference_host.py (`config` / `memo`)
   setenv("VECTORS_NEEDED", "260", 1);
-  REQUIRE(Config::vectors_needed() == 4);                      // uint8 cast (config.hpp:75)
   setenv("MV_THRESHOLD_SQ", "4.0", 1);
-  REQUIRE(Config::mv_threshold_sq() == 4.0);
+  REQUIRE(Config::vectors_needed() == 2 && Config::mv_threshold_sq() == 16.0);
+  // a bad value is a returned error of the pipeline, never an exception out of a worker thread
+  setenv("MTGPU_BATCH_MB", "abc", 1);
+  {
+    PipelineResult r;
+    int rc = run_scan_pipeline([]() -> std::unique_ptr<FrameSource> { throw std::runtime_error("unreachable"); }, 2, r);
+    REQUIRE(rc != 0 && r.error.rfind("configuration:", 0) == 0);
+  }
+  unsetenv("MTGPU_BATCH_MB");
 
   // ---- TaskQueue: FIFO, pop blocks until push or finish, drained queue + finish -> false
   {

@@ -8,6 +8,8 @@ feeds it environment sets and queue scripts and records what the reference answe
   config cases   every Config getter under an environment: defaults, the shipped config/motion_trim.env
                  (its KEY=VALUE lines, read as data), and parse edge cases of std::stoi / stod / stof
                  (prefix parse, hex, whitespace, range errors, the uint8 cast of VECTORS_NEEDED)
+  memo cases     get / setenv / get again inside one process: the getters are function-local statics
+                 (config.hpp:56-59), so the first successful parse sticks and a throwing one is retried
   layout         sizeof / alignof / offsets of TimeSegment and ScanTask
   queue cases    scripted push / pop / finish on TaskQueue, ResultCollector::add / extract order,
                  FFmpegQueue push / pop / finish / is_done / empty
@@ -112,6 +114,44 @@ def queue_scripts():
     return scripts
 
 
+def memo_scripts():
+    rng = random.Random(20261005)
+    getters = [v.lower() for v in CONFIG_VARS]
+    scripts = [
+        ("first_parse_sticks", {}, ["get target_fps", "set TARGET_FPS 10", "get target_fps", "get chunk_duration_sec",
+                                    "set CHUNK_DURATION_SEC 4", "get chunk_duration_sec", "set MAX_GAP_SEC 2",
+                                    "get max_gap_sec", "set MAX_GAP_SEC 3", "get max_gap_sec", "unset MAX_GAP_SEC",
+                                    "get max_gap_sec"]),
+        ("value_at_first_call_not_at_start", {"VECTORS_NEEDED": "4"},
+         ["set VECTORS_NEEDED 1", "get vectors_needed", "set VECTORS_NEEDED 2", "get vectors_needed",
+          "unset VECTORS_NEEDED", "get vectors_needed"]),
+        ("throwing_parse_is_retried", {}, ["set VECTORS_NEEDED abc", "get vectors_needed", "get vectors_needed",
+                                           "set VECTORS_NEEDED 300", "get vectors_needed", "set VECTORS_NEEDED 3",
+                                           "get vectors_needed", "set MV_THRESHOLD_SQ 1e400", "get mv_threshold_sq",
+                                           "set MV_THRESHOLD_SQ 0x10", "get mv_threshold_sq", "set MV_THRESHOLD_SQ 4",
+                                           "get mv_threshold_sq", "set VERTICAL_MASK", "get vertical_mask",
+                                           "unset VERTICAL_MASK", "get vertical_mask", "set VERTICAL_MASK 0.2",
+                                           "get vertical_mask"]),
+        ("default_sticks_too", {}, ["get block_size", "get block_shift", "set BLOCK_SIZE 4", "set BLOCK_SHIFT 2",
+                                    "get block_size", "get block_shift", "get clusters_needed",
+                                    "set CLUSTERS_NEEDED 0", "get clusters_needed"]),
+    ]
+    pool = ["3", "4.75", "abc", "", " 9", "0x1F", "1e400", "300", "-1", "12abc", "99999999999", "0.0625"]
+    for k in range(6):
+        ops = []
+        for _ in range(50):
+            c = rng.random()
+            g = rng.choice(getters)
+            if c < 0.5:
+                ops.append(f"get {g}")
+            elif c < 0.9:
+                ops.append(f"set {g.upper()} {rng.choice(pool)}")
+            else:
+                ops.append(f"unset {g.upper()}")
+        scripts.append((f"random_{k}", {}, ops))
+    return scripts
+
+
 def main():
     if not os.path.exists(PROBE):
         raise SystemExit("build it first: make -C oracle ref")
@@ -130,15 +170,18 @@ def main():
         cases.append(config_case(f"f32:{s!r}", {"VERTICAL_MASK": s}))
     queues = [{"name": n, "script": ops, "answers": run(["queue"], stdin="\n".join(ops) + "\n")}
               for n, ops in queue_scripts()]
+    memos = [{"name": n, "env": env, "script": ops, "answers": run(["memo"], env, stdin="\n".join(ops) + "\n")}
+             for n, env, ops in memo_scripts()]
     doc = {
         "source": "the reference's own config.hpp / types.hpp / src/task_queue.cpp / src/ffmpeg_queue.cpp compiled "
                   "and run in the build container through oracle/ref_host_probe.cpp (make -C oracle ref); "
                   "generator: tests/golden/make_reference_host_vectors.py",
         "answer_format": "config: '<getter> f64|f32|int <value> [0x<bits>]' or '<getter> error <std exception>'; "
-                         "queue: one line per script op",
+                         "queue / memo: one line per script op",
         "layout": run(["layout"]),
         "race": run(["race", "2000", "8"]),
         "config": cases,
+        "memo": memos,
         "queue": queues,
     }
     path = os.path.join(HERE, "reference_host_vectors.json")

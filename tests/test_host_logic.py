@@ -36,6 +36,7 @@ def test_config_getters_follow_env(monkeypatch):
     for k in ["MV_THRESHOLD_SQ", "BLOCK_SIZE", "BLOCK_SHIFT", "VECTORS_NEEDED", "CLUSTERS_NEEDED",
               "VERTICAL_MASK", "MAX_GAP_SEC", "PADDING_SEC", "CHUNK_DURATION_SEC", "TARGET_FPS", "MIN_SAVINGS_PCT"]:
         monkeypatch.delenv(k, raising=False)
+    c.forget()
     # code defaults (include/motion_trim/config.hpp:56-125)
     assert (c.mv_threshold_sq(), c.block_size(), c.block_shift(), c.vectors_needed(), c.clusters_needed()) == \
         (16.0, 16, 4, 2, 2)
@@ -48,11 +49,16 @@ def test_config_getters_follow_env(monkeypatch):
     monkeypatch.setenv("MV_THRESHOLD_SQ", "4.0")
     monkeypatch.setenv("VECTORS_NEEDED", "4")
     monkeypatch.setenv("TARGET_FPS", "10.0")
+    # read once per process, like the reference's function-local statics (config.hpp:56-59): still the defaults
+    assert (c.mv_threshold_sq(), c.vectors_needed(), c.target_fps()) == (16.0, 2, 0.0)
+    c.forget()                                           # "a new process"
     p = m.ScanParams.from_config(1920, 1080)
     assert (p.mv_threshold_sq, p.vectors_needed) == (4.0, 4)
     assert c.target_fps() == 10.0
     monkeypatch.setenv("VECTORS_NEEDED", "260")          # uint8 cast
+    c.forget()
     assert c.vectors_needed() == 4 and m.ScanParams.from_config(1920, 1080).vectors_needed == 4
+    c.forget()
     mp = m.MergeParams(duration=60.0)
     assert (mp.max_gap_sec, mp.padding_sec, mp.min_savings_pct) == (5.0, 0.5, 5.0)
 

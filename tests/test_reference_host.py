@@ -64,30 +64,55 @@ def python_config_answers(env):
     import struct
     saved = {k: os.environ.pop(k, None) for k in CONFIG_VARS}
     os.environ.update(env)
-    lines = []
+    m.config.forget()                           # a fresh process, as far as the getters can tell
     try:
-        for name, fn in GETTERS.items():
-            try:
-                v = fn()
-            except ValueError:
-                lines.append(f"{name} error invalid_argument")
-                continue
-            except OverflowError:
-                lines.append(f"{name} error out_of_range")
-                continue
-            if name == "vertical_mask":
-                bits = struct.unpack("<I", struct.pack("<f", v))[0]
-                lines.append(f"{name} f32 {bits:#010x}")
-            elif isinstance(v, float):
-                bits = struct.unpack("<Q", struct.pack("<d", v))[0]
-                lines.append(f"{name} f64 {bits:#018x}")
-            else:
-                lines.append(f"{name} int {v}")
+        return [_python_get(name) for name in GETTERS]
     finally:
         for k in CONFIG_VARS:
             os.environ.pop(k, None)
             if saved[k] is not None:
                 os.environ[k] = saved[k]
+        m.config.forget()
+
+
+def _python_get(name):
+    import struct
+    try:
+        v = GETTERS[name]()
+    except ValueError:
+        return f"{name} error invalid_argument"
+    except OverflowError:
+        return f"{name} error out_of_range"
+    if name == "vertical_mask":
+        return f"{name} f32 {struct.unpack('<I', struct.pack('<f', v))[0]:#010x}"
+    if isinstance(v, float):
+        return f"{name} f64 {struct.unpack('<Q', struct.pack('<d', v))[0]:#018x}"
+    return f"{name} int {v}"
+
+
+def python_memo_answers(script):
+    """The probe's `memo` output, produced by mvtrim_amd.config: one process, environment edited between gets."""
+    saved = {k: os.environ.pop(k, None) for k in CONFIG_VARS}
+    m.config.forget()
+    lines = []
+    try:
+        for ln in script:
+            op, _, rest = ln.partition(" ")
+            if op == "get":
+                lines.append(_python_get(rest))
+            elif op == "set":
+                k, _, v = rest.partition(" ")
+                os.environ[k] = v
+                lines.append("set ok")
+            elif op == "unset":
+                os.environ.pop(rest, None)
+                lines.append("unset ok")
+    finally:
+        for k in CONFIG_VARS:
+            os.environ.pop(k, None)
+            if saved[k] is not None:
+                os.environ[k] = saved[k]
+        m.config.forget()
     return lines
 
 
@@ -113,6 +138,21 @@ def test_python_config_matches_reference(case):
 def test_cpp_host_config_matches_reference(host_probe):
     for case in VEC["config"]:
         assert run(host_probe, ["config"], case["env"]) == case["answers"], case["name"]
+
+
+@pytest.mark.parametrize("case", VEC["memo"], ids=[c["name"] for c in VEC["memo"]])
+def test_config_memoisation_matches_reference(host_probe, case):
+    """get / setenv / get again inside ONE process: the reference's getters are function-local statics
+    (config.hpp:56-59) — the first successful parse sticks, a throwing parse is retried.  Answers recorded from
+    the reference's own config.hpp; replayed against the C++ host layer and the Python mirror."""
+    script = "\n".join(case["script"]) + "\n"
+    assert run(host_probe, ["memo"], case["env"], stdin=script) == case["answers"]
+    if not case["env"]:
+        assert python_memo_answers(case["script"]) == bits_only_mixed(case["answers"])
+
+
+def bits_only_mixed(lines):
+    return [ln if ln.split()[1] in ("ok", "int", "error") else bits_only([ln])[0] for ln in lines]
 
 
 def test_shipped_env_file_values():
@@ -212,6 +252,22 @@ def test_live_against_reference_binary(host_probe):
         script = "\n".join(ops) + "\n"
         assert run(host_probe, ["queue"], stdin=script) == run(REF_PROBE, ["queue"], stdin=script)
     assert run(REF_PROBE, ["layout"]) == VEC["layout"]
+    pool = ["3", "4.75", "abc", "", " 9", "0x1F", "1e400", "300", "-1", "12abc", "99999999999"]
+    for _ in range(20):
+        ops = []
+        for _ in range(40):
+            c = rng.random()
+            name = rng.choice(list(GETTERS))
+            if c < 0.5:
+                ops.append(f"get {name}")
+            elif c < 0.9:
+                ops.append(f"set {name.upper()} {rng.choice(pool)}")
+            else:
+                ops.append(f"unset {name.upper()}")
+        script = "\n".join(ops) + "\n"
+        ref = run(REF_PROBE, ["memo"], stdin=script)
+        assert run(host_probe, ["memo"], stdin=script) == ref
+        assert python_memo_answers(ops) == bits_only_mixed(ref)
 
 
 def test_cpp_host_queues_under_thread_sanitizer(tmp_path):
