@@ -96,6 +96,14 @@ def free_port():
     return port
 
 
+def rank_log_path(rank):
+    """bench_rank{r}.err: every rank of an N > 1 run leaves its own evidence (device held, frames scanned, kernel
+    time, or the traceback that ended it) — under gpurun_out/ when that exists (it is what travels back from a
+    GPU box), else beside bench.py."""
+    d = os.path.join(ROOT, "gpurun_out")
+    return os.path.join(d if os.path.isdir(d) else ROOT, f"bench_rank{rank}.err")
+
+
 def launch_ranks(a, argv, environ=None, popen=subprocess.Popen):
     """Start a.gpus fresh rank processes of this script (the parent never touches HIP, and no
     process that has is ever re-exec'ed), wait for all of them; rank 0's stdout (the JSON line)
@@ -103,7 +111,15 @@ def launch_ranks(a, argv, environ=None, popen=subprocess.Popen):
     environ = dict(os.environ if environ is None else environ)
     envs = rank_environments(a.gpus, environ, free_port())
     cmd = [sys.executable, os.path.abspath(__file__)] + list(argv)
-    procs = [popen(cmd, env=e, stdout=None if r == 0 else subprocess.DEVNULL) for r, e in enumerate(envs)]
+    # rank 0 keeps this process's stdout / stderr; the other ranks' stderr is kept in files (a rank that dies
+    # takes the run down: the reason must survive it)
+    procs = []
+    for r, e in enumerate(envs):
+        if r == 0:
+            procs.append(popen(cmd, env=e, stdout=None))
+        else:
+            with open(rank_log_path(r) + ".stderr.log", "wb") as errf:
+                procs.append(popen(cmd, env=e, stdout=subprocess.DEVNULL, stderr=errf))
     rc = 0
     pending = list(procs)
     while pending:
@@ -241,7 +257,71 @@ def host_fed_leg(spec, mv, off):
     out["pcie_GBps"] = {"compact8_zero_copy": out["compact8_zero_copy_frames_per_s"] * (8 * recs + 10) / 1e9,
                         "aos40_copy": out["aos40_copy_frames_per_s"] * (40 * recs + 10) / 1e9,
                         "note": "PCIe gen5 x16: 64 GB/s raw, about 55 GB/s achievable one way"}
+    out["note"] = ("PCIe-inclusive: what a real decode pipeline gets per GPU; the link, not the kernel, is the limit "
+                   "(the resident `value` is ~30x higher)")
+    try:
+        out["config4_64_streams"] = host_fed_batch64(exe)
+    except Exception as e:      # informational
+        out["config4_64_streams"] = {"error": repr(e)}
     return out
+
+
+def host_fed_batch64(exe, n=12, reps=250):
+    """BASELINE config 4 through the product-shaped path on ONE device: 64 distinct-seed 1080p dense8x8 streams
+    (12 distinct frames each, presented 250x = 3000 frames per stream) through process_batch of the C++ host
+    layer at 64 streams x 1 worker and 16 streams x 4 workers; default staging (compact, zero-copy)."""
+    import tempfile
+    import mvtrim_amd as m
+    from mvtrim_amd import synth
+    d = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    res = {"source": f"64 distinct-seed {n}-frame 1080p dense8x8 streams, each repeated {reps}x "
+                     f"({64 * n * reps} frames per run), page-cache resident", "gpus": 1}
+    with tempfile.TemporaryDirectory(dir=d) as tmp:
+        paths = []
+        for k in range(64):
+            spec = synth.spec_1080p(seed=2000 + k, sub=2)
+            spec.events = [synth.Event(1, 1 + n // 2, 10 + k, 12 + k % 40, 4, 3, 9, 2)]
+            frames = [synth.gen_frame(spec, i) for i in range(1, 1 + n)]
+            path = os.path.join(tmp, f"cam{k:02d}.mtmv")
+            m.mvfile.write_mtmv(path, 1920, 1080, 1, spec.tb_den, spec.fps, n / spec.fps,
+                                [spec.pts_ticks(i) for i in range(n)], frames, key=[1] * n)
+            paths.append(path)
+        env = dict(os.environ, CHUNK_DURATION_SEC="10", TARGET_FPS="0")
+        for k in ("MTGPU_BATCH_MB", "MTGPU_STAGING"):
+            env.pop(k, None)
+        env["HIP_VISIBLE_DEVICES"] = (os.environ.get("HIP_VISIBLE_DEVICES") or "0").split(",")[0]
+        for streams, threads in ((64, 1), (16, 4)):
+            r = subprocess.run([exe] + paths + ["--streams", str(streams), "--threads", str(threads), "--repeat",
+                                                str(reps), "--summary", "--outdir", tmp], capture_output=True,
+                               text=True, env=env, timeout=300)
+            if r.returncode != 0:
+                res[f"{streams}x{threads}"] = {"error": (r.stderr or "mtgpu_scan_file failed")[-300:]}
+                continue
+            lines = [json.loads(ln) for ln in r.stdout.strip().splitlines()]
+            s = [j["batch_summary"] for j in lines if "batch_summary" in j][0]
+            jobs = [j for j in lines if "batch_summary" not in j]
+            workers = streams * threads
+            wall = max(s["wall_us"], 1) * 1e-6
+            busy = max(s["decode_us"] + s["analyze_us"], 1)
+            res[f"{streams}x{threads}"] = {
+                "streams": streams, "workers_per_stream": threads, "frames": s["frames_scanned"], "jobs": s["jobs"],
+                "frames_per_s_wall": s["frames_scanned"] / wall,          # includes creating 64xT contexts + pinned pipes
+                # `streams` videos are in flight at any time: their mean own rate (all workers initialised ->
+                # last result of that video) x streams = the steady-state rate, without context / pipe set-up
+                "frames_per_s_steady": (float(np.mean([j["frames_scanned"] / max(j["scan_work_us"] * 1e-6, 1e-9)
+                                                       for j in jobs])) * streams) if jobs else None,
+                "wall_ms": s["wall_us"] / 1e3,
+                "worker_time_share": {"init": s["init_us"] / (workers * wall * 1e6),
+                                      "reading_frames": s["decode_us"] / busy,
+                                      "copy_out_to_pinned": s["copy_us"] / busy,
+                                      "submit_calls": s["submit_us"] / busy,
+                                      "waiting_for_gpu": s["wait_us"] / busy},
+                "held_on_one_device": {"contexts": s["held"]["contexts"], "pipes": s["held"]["pipes"],
+                                       "hip_streams": s["held"]["hip_streams"], "hip_events": s["held"]["hip_events"],
+                                       "mem_pools": s["held"]["mem_pools"],
+                                       "pinned_MiB": s["held"]["pinned_bytes"] / 2**20,
+                                       "device_MiB": s["held"]["device_bytes"] / 2**20}}
+    return res
 
 
 def roofline_of(alg_bytes, kern_ms):
@@ -300,7 +380,38 @@ def other_workloads(dev, distinct):
 
 # ---------------------------------------------------------------------------- one rank
 
+def device_identity(torch, dev, rank, local):
+    """Which physical device this rank holds, for the driver to check (N ranks must show N distinct bus ids)."""
+    p = torch.cuda.get_device_properties(dev)
+    ident = {"rank": rank, "local_rank": local, "device_index": dev.index, "name": p.name, "pid": os.getpid(),
+             "visible_devices": os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES")),
+             "device_count": torch.cuda.device_count()}
+    try:
+        ident["pci_bus_id"] = "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+    except AttributeError:
+        ident["pci_bus_id"] = None
+    try:
+        ident["uuid"] = str(p.uuid)
+    except AttributeError:
+        ident["uuid"] = None
+    return ident
+
+
 def run_rank(a):
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1:
+        return _run_rank(a)
+    try:
+        return _run_rank(a)
+    except BaseException:
+        import traceback
+        with open(rank_log_path(rank), "a") as f:
+            f.write(f"rank {rank} of {world} FAILED\n" + traceback.format_exc())
+        raise
+
+
+def _run_rank(a):
     # stdout carries exactly ONE line, the JSON: anything libraries print on fd 1 (gloo's connection
     # notes, RCCL info lines) goes to stderr instead
     sys.stdout.flush()
@@ -320,7 +431,10 @@ def run_rank(a):
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    ident = device_identity(torch, dev, rank, local)
     if world > 1:
+        with open(rank_log_path(rank), "w") as f:
+            f.write(json.dumps({"stage": "start", **ident}) + "\n")
         if a.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -404,6 +518,7 @@ def run_rank(a):
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    dt_local = dt
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -425,17 +540,33 @@ def run_rank(a):
     read_ceiling = nbytes / (c0.elapsed_time(c1) / 10 * 1e-3) / 1e9
     flags_host = d_flags.cpu().numpy()
 
+    # what each rank held and did, gathered for the driver (N = 1: one entry)
+    ident.update({"frames_scanned": a.frames * a.steps, "kernel_ms": kern_ms, "wall_s": dt_local,
+                  "motion_frames_in_batch": int(flags_host.sum()), "read_ceiling_GBps": read_ceiling})
+    ranks = [ident]
+    if world > 1:
+        with open(rank_log_path(rank), "a") as f:
+            f.write(json.dumps({"stage": "timed", **ident}) + "\n")
+        ranks = [None] * world
+        dist.all_gather_object(ranks, ident)
+
     if rank == 0:
         total_frames = a.frames * world * a.steps
         value = total_frames / dt
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # HBM bytes/launch from a --pmc run, if committed
+        # HBM bytes per launch: NOT measured by this run (PMC counters need rocprofv3 around the process) —
+        # replayed from the committed summary of the builder's own --pmc passes over this same command
+        traffic, traffic_source = None, None
+        tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tp):
             try:
                 rec = json.load(open(tp)).get(f"{a.workload}:{a.frames}")
-                traffic = rec["hbm_bytes_per_launch"] if rec else None
+                if rec and a.params == rec.get("params", "code_defaults"):
+                    traffic = rec["hbm_bytes_per_launch"]
+                    traffic_source = ("replayed, not measured in this run: profiles/pmc_traffic.json "
+                                      f"[{a.workload}:{a.frames}], builder-run rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                      f"passes (gfx950 x2 FETCH correction), {rec.get('collected', 'round 2')}")
             except Exception:
-                traffic = None
+                traffic, traffic_source = None, None
         cpu = None
         others = None
         host = None
@@ -460,7 +591,7 @@ def run_rank(a):
             except Exception as e:          # e.g. out of memory on a smaller device: keep the headline
                 others = [{"error": repr(e)}]
         roof = roofline_of(alg_bytes, kern_ms)
-        roof.update({"traffic": traffic, "measured_read_ceiling": read_ceiling,
+        roof.update({"traffic": traffic, "traffic_source": traffic_source, "measured_read_ceiling": read_ceiling,
                      "frac_of_measured_ceiling": roof["achieved"] / read_ceiling})
         line = {
             "metric": "MV-scan frames/sec at 1080p grid" if a.workload.startswith("1080p") else "MV-scan frames/sec",
@@ -481,6 +612,9 @@ def run_rank(a):
             "other_workloads": others,
             "host_fed": host,
             "motion_frames_in_batch": int(flags_host.sum()),
+            "ranks": ranks,
+            "distinct_devices": len({(r or {}).get("pci_bus_id") or (r or {}).get("uuid") or i
+                                     for i, r in enumerate(ranks)}),
         }
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     os.close(json_fd)
@@ -504,40 +638,54 @@ def host_cpu_info():
 
 
 def cpu_baseline(params, mv, off, gpu_flags, budget_s, workload):
-    """The C oracle (kind "port": our restatement of the reference's check_frame) timed on
-    this host's cores on a bounded sample: the `distinct` generated frames, scanned
-    repeatedly until ~budget_s seconds of wall time; frames split over the usable cores, capped
-    at 16 = a 1-GPU box's CPU share (one private grid per thread, the reference's
-    one-scanner-per-worker model)."""
+    """The C oracle (kind "port": our restatement of the reference's check_frame) timed on this host's
+    cores on a bounded sample, as SURVEY.md 8(d) defines the CPU baseline: 1 thread, 16 threads (a 1-GPU
+    box's CPU share) and ALL usable cores — frames split statically over pthreads, one private grid per
+    thread (the reference's one-scanner-per-worker model, src/pipeline.cpp:186-197).  The sample is the
+    `distinct` generated frames tiled so that every thread streams several MB per pass; each leg repeats
+    the pass until its share of ~budget_s seconds of wall time is used.  `value` = the 16-thread leg."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_binding as ob     # checker / baseline only
     model, cores_total, cores_usable = host_cpu_info()
-    cores = min(cores_usable, 16)
+    share = min(cores_usable, 16)
     n0 = len(off) - 1
-    flags = ob.scan_frames(params, mv, off, None, nthreads=cores)       # warm-up + parity check
+    flags = ob.scan_frames(params, mv, off, None, nthreads=share)       # warm-up + parity check
     assert np.array_equal(flags, gpu_flags), "GPU flags differ from the oracle on the bench tile"
-    # tile the sample so that every thread streams tens of MB per pass (beyond its L2)
-    tile = max(1, (64 * cores + n0 - 1) // n0)
+    # >= 64 frames per thread of the 16-thread leg, >= 8 per thread of the all-core leg (10 MB: beyond its L2)
+    want = max(64 * share, 8 * cores_usable)
+    tile = max(1, (want + n0 - 1) // n0)
     counts = np.tile(np.diff(off.astype(np.int64)), tile)
     off = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
     mv = np.tile(mv, tile)
     n = len(off) - 1
-    t0 = time.perf_counter()
-    ob.scan_frames(params, mv, off, None, nthreads=1)
-    t1 = time.perf_counter() - t0
-    reps, t_mt = 0, 0.0
-    t0 = time.perf_counter()
-    while True:
-        ob.scan_frames(params, mv, off, None, nthreads=cores)
-        reps += 1
-        t_mt = time.perf_counter() - t0
-        if t_mt > budget_s or reps >= 10000:
-            break
-    return {"value": n * reps / t_mt, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{n} {workload} frames ({n0} distinct, {mv.nbytes / 1e6:.0f} MB) x {reps} passes "
-                      f"({t_mt:.1f} s wall), oracle/mt_oracle.c scan, {cores} pthreads",
-            "value_1core": n / t1, "host_cpu": model, "host_cores_total": cores_total,
-            "host_cores_usable": cores_usable}
+
+    def leg(threads, seconds):
+        ob.scan_frames(params, mv, off, None, nthreads=threads)        # touch every page from these threads once
+        reps, t0 = 0, time.perf_counter()
+        while True:
+            ob.scan_frames(params, mv, off, None, nthreads=threads)
+            reps += 1
+            dt = time.perf_counter() - t0
+            if dt > seconds or reps >= 10000:
+                return n * reps / dt, reps, dt
+
+    legs = [(1, 0.15 * budget_s), (share, 0.45 * budget_s)]
+    if cores_usable > share:
+        legs.append((cores_usable, 0.40 * budget_s))
+    res = {t: leg(t, sec) for t, sec in legs}
+    v16, reps16, dt16 = res[share]
+    out = {"value": v16, "unit": "frames/s", "cores": share, "kind": "port",
+           "sample": f"{n} {workload} frames ({n0} distinct, {mv.nbytes / 1e6:.0f} MB) x {reps16} passes "
+                     f"({dt16:.1f} s wall), oracle/mt_oracle.c scan, {share} pthreads",
+           "value_1core": res[1][0], "sample_1core": f"{res[1][1]} passes, {res[1][2]:.1f} s",
+           "host_cpu": model, "host_cores_total": cores_total, "host_cores_usable": cores_usable,
+           "GBps": {"1": res[1][0] * mv.nbytes / n / 1e9, str(share): v16 * mv.nbytes / n / 1e9}}
+    if cores_usable in res and cores_usable != share:
+        va, ra, da = res[cores_usable]
+        out.update({"value_all_cores": va, "cores_all": cores_usable,
+                    "sample_all_cores": f"{ra} passes, {da:.1f} s, {cores_usable} pthreads (every usable hardware thread)"})
+        out["GBps"][str(cores_usable)] = va * mv.nbytes / n / 1e9
+    return out
 
 
 def main(argv=None):

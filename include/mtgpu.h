@@ -68,6 +68,27 @@ int mtgpu_create(const mt_scan_params *params, int device, mtgpu_ctx **out);
 void mtgpu_destroy(mtgpu_ctx *ctx);
 int mtgpu_get_params(const mtgpu_ctx *ctx, mt_scan_params *out);
 
+/*
+ * What a context holds on the device, and how to give it back.  No reference counterpart: the
+ * reference's per-scanner memory is the grid_votes vector (src/motion_scanner.cpp:199), which lives
+ * in LDS here.  Launch scratch (the spill queue of banded plans: 4 bytes per record of the largest
+ * batch scanned so far; slice tiles; the merge workspace: 24 bytes per timestamp) comes from a
+ * private stream-ordered pool that KEEPS freed blocks until mtgpu_trim or mtgpu_destroy, so that a
+ * steady stream of batches never re-maps memory.  A host that scans one huge batch
+ * and then idles should call mtgpu_trim; the C++ host layer does so between the videos of a batch.
+ */
+typedef struct mtgpu_ctx_stats {
+  uint64_t staging_device_bytes;  /* grow-only device buffers of the HOST-pointer entry points   */
+  uint64_t pool_reserved_bytes;   /* device memory the scratch pool holds right now             */
+  uint64_t pool_reserved_high;    /* its high-water mark                                        */
+  uint32_t hip_streams;           /* streams owned by the context (1)                           */
+  uint32_t private_pool;          /* 1: scratch from the private pool; 0: device default pool   */
+} mtgpu_ctx_stats;
+int mtgpu_get_stats(mtgpu_ctx *ctx, mtgpu_ctx_stats *out);
+/* Return the scratch pool's unused blocks to the device.  Call it when nothing of this context
+ * is in flight (between videos); scans that follow simply map scratch again. */
+int mtgpu_trim(mtgpu_ctx *ctx);
+
 /* Launch plan chosen for the context's grid (for reports and tests). */
 typedef struct mtgpu_plan {
   int32_t block_threads;   /* workgroup size                                      */
@@ -235,6 +256,17 @@ int mtgpu_pipe_submit(mtgpu_pipe *pipe, mtgpu_batch *batch);
 int mtgpu_pipe_collect(mtgpu_pipe *pipe, mtgpu_batch **out, const uint8_t **flags,
                        const double **pts, const uint64_t **tags, uint32_t *n_frames);
 int mtgpu_pipe_release(mtgpu_pipe *pipe, mtgpu_batch *batch);
+
+/* What a pipe costs: every worker thread of the reference's N x S model (src/pipeline.cpp:186-197,
+ * src/batch_processor.cpp:152-157) owns one pipe, so 64 streams x T workers multiply these. */
+typedef struct mtgpu_pipe_stats {
+  uint64_t pinned_bytes;   /* page-locked host memory: staging blocks + pts / tag / flag arrays    */
+  uint64_t device_bytes;   /* device mirrors of the staging (0 with MT_LAYOUT_ZERO_COPY)           */
+  uint64_t submits;        /* batches submitted so far                                             */
+  uint32_t n_buffers;      /* staging batches = HIP streams = HIP events owned by the pipe         */
+  int32_t layout;          /* MT_LAYOUT_* flags                                                    */
+} mtgpu_pipe_stats;
+int mtgpu_pipe_get_stats(mtgpu_pipe *pipe, mtgpu_pipe_stats *out);
 
 /* ---------------------------------------------------------------------------
  * Multi-GPU exchange for hosts that run one process per GPU without torch.distributed:

@@ -60,6 +60,16 @@ class PlanC(C.Structure):
                 ("counter_mode", C.c_int32), ("_pad", C.c_int32)]
 
 
+class CtxStatsC(C.Structure):
+    _fields_ = [("staging_device_bytes", C.c_uint64), ("pool_reserved_bytes", C.c_uint64),
+                ("pool_reserved_high", C.c_uint64), ("hip_streams", C.c_uint32), ("private_pool", C.c_uint32)]
+
+
+class PipeStatsC(C.Structure):
+    _fields_ = [("pinned_bytes", C.c_uint64), ("device_bytes", C.c_uint64), ("submits", C.c_uint64),
+                ("n_buffers", C.c_uint32), ("layout", C.c_int32)]
+
+
 assert C.sizeof(ScanParamsC) == 32 and C.sizeof(MergeResultC) == 40
 
 # name -> (restype, argtypes): every symbol include/mtgpu.h declares.
@@ -72,6 +82,8 @@ ABI = {
     "mtgpu_create": (C.c_int, [C.POINTER(ScanParamsC), C.c_int, C.POINTER(C.c_void_p)]),
     "mtgpu_destroy": (None, [C.c_void_p]),
     "mtgpu_get_params": (C.c_int, [C.c_void_p, C.POINTER(ScanParamsC)]),
+    "mtgpu_get_stats": (C.c_int, [C.c_void_p, C.POINTER(CtxStatsC)]),
+    "mtgpu_trim": (C.c_int, [C.c_void_p]),
     "mtgpu_get_plan": (C.c_int, [C.c_void_p, C.POINTER(PlanC)]),
     "mtgpu_plan_preview": (C.c_int, [C.POINTER(ScanParamsC), C.c_int, C.c_int, C.POINTER(PlanC)]),
     "mtgpu_set_slices": (C.c_int, [C.c_void_p, C.c_int]),
@@ -101,6 +113,7 @@ ABI = {
     "mtgpu_pipe_collect": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                      C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint32)]),
     "mtgpu_pipe_release": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mtgpu_pipe_get_stats": (C.c_int, [C.c_void_p, C.POINTER(PipeStatsC)]),
     "mtgpu_comm_unique_id": (C.c_int, [C.c_void_p]),
     "mtgpu_comm_create": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "mtgpu_comm_destroy": (None, [C.c_void_p]),

@@ -184,9 +184,13 @@ class MtmvFile {   // one mmap shared by all sources of a video (the reference m
     hdr = reinterpret_cast<const MtmvHeader *>(base_);
     if (std::memcmp(hdr->magic, "MTMV1\0\0\0", 8) != 0) throw std::runtime_error("not an mtmv file");
     frames = reinterpret_cast<const MtmvFrameRec *>(base_ + sizeof(MtmvHeader));
+    if (hdr->n_frames > (size_ - sizeof(MtmvHeader)) / sizeof(MtmvFrameRec) ||
+        hdr->n_records > (size_ - sizeof(MtmvHeader) - sizeof(MtmvFrameRec) * hdr->n_frames) / 40ull)
+      throw std::runtime_error("truncated mtmv file: " + path);
+    for (uint64_t i = 0; i < hdr->n_frames; ++i)      // a damaged frame table must not send a worker outside the mapping
+      if (frames[i].rec_off > hdr->n_records || frames[i].n_rec > hdr->n_records - frames[i].rec_off)
+        throw std::runtime_error("corrupt mtmv frame table: " + path);
     records = base_ + sizeof(MtmvHeader) + sizeof(MtmvFrameRec) * hdr->n_frames;
-    if (sizeof(MtmvHeader) + sizeof(MtmvFrameRec) * hdr->n_frames + 40ull * hdr->n_records > size_)
-      throw std::runtime_error("truncated mtmv file");
   }
   ~MtmvFile() { if (base_ && base_ != MAP_FAILED) munmap(const_cast<uint8_t *>(base_), size_); if (fd_ >= 0) close(fd_); }
   MtmvFile(const MtmvFile &) = delete;
@@ -225,6 +229,17 @@ class MtmvSource : public FrameSource {
 // The GPU side of one worker: a scan context (cfg + launch plan) and its pinned pipe.  Kept
 // separate from the decoder-facing scanner so that a batch worker can reuse it for the next
 // video of the same size instead of re-pinning staging memory per file.
+// What the GPU side of the host layer holds: one context + one pinned pipe per worker thread.
+struct Resources {
+  uint64_t contexts = 0, pipes = 0, hip_streams = 0, hip_events = 0, mem_pools = 0;
+  uint64_t pinned_bytes = 0, device_bytes = 0, pool_reserved_high = 0, submits = 0;
+  void add(const Resources &o) {
+    contexts += o.contexts; pipes += o.pipes; hip_streams += o.hip_streams; hip_events += o.hip_events;
+    mem_pools += o.mem_pools; pinned_bytes += o.pinned_bytes; device_bytes += o.device_bytes;
+    pool_reserved_high += o.pool_reserved_high; submits += o.submits;
+  }
+};
+
 class GpuBackend {
   mtgpu_ctx *ctx_ = nullptr;
   mtgpu_pipe *pipe_ = nullptr;
@@ -241,6 +256,23 @@ class GpuBackend {
   }
   mtgpu_ctx *ctx() { return ctx_; }
   mtgpu_pipe *pipe() { return pipe_; }
+  Resources resources() {
+    Resources r;
+    mtgpu_ctx_stats cs;
+    mtgpu_pipe_stats ps;
+    if (ctx_ && mtgpu_get_stats(ctx_, &cs) == MT_OK) {
+      r.contexts = 1; r.hip_streams += cs.hip_streams; r.mem_pools = cs.private_pool;
+      r.device_bytes += cs.staging_device_bytes + cs.pool_reserved_high; r.pool_reserved_high = cs.pool_reserved_high;
+    }
+    if (pipe_ && mtgpu_pipe_get_stats(pipe_, &ps) == MT_OK) {
+      r.pipes = 1; r.hip_streams += ps.n_buffers; r.hip_events += ps.n_buffers;
+      r.pinned_bytes += ps.pinned_bytes; r.device_bytes += ps.device_bytes; r.submits = ps.submits;
+    }
+    return r;
+  }
+  // between two videos: hand the scratch pool's cached blocks back (the spill queue of a banded plan is
+  // 4 bytes per record of the largest batch ever scanned — per context, times N x S workers)
+  void trim() { if (ctx_) (void)mtgpu_trim(ctx_); }
   // cfg/grid derivation of MotionScanner::initialize (motion_scanner.cpp:184-199) + device setup;
   // a backend already set up for this frame size and device is reused as it is.
   bool ensure(int width, int height, int device, uint64_t batch_records, uint32_t batch_frames, int n_buffers,
@@ -270,6 +302,7 @@ class GpuMotionScanner {   // public shape of MotionScanner (motion_scanner.hpp:
   int inflight_ = 0;
   std::string err_;
   long copy_us_ = 0, submit_us_ = 0, wait_us_ = 0;   // inside analyze_us: copy-out / submit calls / waiting for the GPU
+  uint64_t frames_fed_ = 0;                           // frames that reached check_frame (after the filter of :357-371)
   static long since(std::chrono::high_resolution_clock::time_point t0) {
     return (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::high_resolution_clock::now() - t0).count();
   }
@@ -315,6 +348,7 @@ class GpuMotionScanner {   // public shape of MotionScanner (motion_scanner.hpp:
       int rc = mtgpu_batch_add_frame(cur_, f.mv, f.mv_bytes, f.has_side_data ? 1 : 0, pts, 0);
       copy_us_ += since(c0);
       if (rc == MT_ERR_CAPACITY) { if (!submit()) return false; continue; }
+      if (rc == MT_OK) ++frames_fed_;
       return ok(rc);
     }
   }
@@ -338,6 +372,7 @@ class GpuMotionScanner {   // public shape of MotionScanner (motion_scanner.hpp:
   long copy_us() const { return copy_us_; }
   long submit_us() const { return submit_us_; }
   long wait_us() const { return wait_us_; }
+  uint64_t frames_fed() const { return frames_fed_; }
   mtgpu_ctx *context() { return be_->ctx(); }
 
   // batch_records == 0: sized from the source and the staging layout — MTGPU_BATCH_MB MiB of
@@ -413,6 +448,7 @@ struct PipelineResult {
   std::vector<mt_segment> segments;   // what FFmpegJob::segments would carry (pipeline.cpp:366, 396)
   mt_merge_result merge{};
   size_t motion_frames = 0;           // pooled timestamps before sort/unique (pipeline.cpp:294-295)
+  uint64_t frames_scanned = 0;        // frames that went through check_frame on the GPU, all workers
   std::vector<double> timestamps;     // those timestamps, in pooling order (ResultCollector::extract, :268)
   int chunks = 0, threads = 0;
   long seek_us = 0, decode_us = 0, analyze_us = 0;   // summed over workers, as pipeline.cpp:229-233
@@ -455,6 +491,7 @@ int run_scan_pipeline(MakeSource make_source, int num_threads, PipelineResult &o
   for (double t = 0; t < duration; t += chunk)                           // :163-167
     tasks.push({t, std::min(t + chunk, duration), chunk_id++});
   std::atomic<long> seek_us{0}, decode_us{0}, analyze_us{0}, init_us{0}, copy_us{0}, submit_us{0}, wait_us{0};
+  std::atomic<uint64_t> frames_scanned{0};
   const auto wall0 = std::chrono::high_resolution_clock::now();
   std::mutex err_mu;
   std::vector<std::thread> workers;
@@ -508,6 +545,7 @@ int run_scan_pipeline(MakeSource make_source, int num_threads, PipelineResult &o
         }
         seek_us += s; decode_us += d; analyze_us += a;
         copy_us += scanners[i]->copy_us(); submit_us += scanners[i]->submit_us(); wait_us += scanners[i]->wait_us();
+        frames_scanned += scanners[i]->frames_fed();
       } catch (const std::exception &e) {
         fail_with(std::string("worker ") + std::to_string(i) + ": " + e.what());
       } catch (...) {
@@ -521,6 +559,7 @@ int run_scan_pipeline(MakeSource make_source, int num_threads, PipelineResult &o
   out.threads = num_threads;
   out.seek_us = seek_us; out.decode_us = decode_us; out.analyze_us = analyze_us; out.init_us = init_us;
   out.copy_us = copy_us; out.submit_us = submit_us; out.wait_us = wait_us;
+  out.frames_scanned = frames_scanned;
   {
     const auto wall1 = std::chrono::high_resolution_clock::now();
     out.scan_wall_us = (long)std::chrono::duration_cast<std::chrono::microseconds>(wall1 - wall0).count();
@@ -576,20 +615,39 @@ class JobQueue {   // producer/consumer queue of finished scans, as ffmpeg_queue
 // (s * threads_per_stream + i) % n_devices, so concurrent streams spread over the node's GPUs.
 // Every finished scan is pushed to `jobs` (no motion -> no job, as pipeline.cpp:308-319).
 // open_source(path) must return a factory of per-worker FrameSources for that file.
+struct BatchSummary {   // what a whole process_batch run did and what it held (reported, never decided on)
+  int streams = 0, threads_per_stream = 0;
+  size_t videos = 0, jobs = 0, failed = 0;
+  uint64_t frames_scanned = 0;
+  long wall_us = 0;                                        // first stream thread started -> last one finished
+  long init_us = 0, decode_us = 0, analyze_us = 0, copy_us = 0, submit_us = 0, wait_us = 0;   // summed over all workers
+  Resources held;                                          // summed over the S x T backends alive at the end
+};
+
 template <class OpenSource>
 int process_batch(const std::vector<std::string> &files, const std::string &output_dir, int parallel_streams,
-                  int threads_per_stream, OpenSource open_source, JobQueue &jobs, std::vector<std::string> *errors) {
+                  int threads_per_stream, OpenSource open_source, JobQueue &jobs, std::vector<std::string> *errors,
+                  BatchSummary *summary = nullptr) {
   parallel_streams = std::max(1, std::min<int>(parallel_streams, (int)files.size()));
   threads_per_stream = std::max(1, threads_per_stream);
-  std::mutex q_mu, e_mu;
+  std::mutex q_mu, e_mu, s_mu;
   size_t next = 0;
   std::atomic<int> failed{0};
+  BatchSummary sum;
+  sum.streams = parallel_streams;
+  sum.threads_per_stream = threads_per_stream;
+  sum.videos = files.size();
+  const auto wall0 = std::chrono::high_resolution_clock::now();
   std::vector<std::thread> streams;
   for (int s = 0; s < parallel_streams; ++s) {
     streams.emplace_back([&, s] {
       // this stream's workers keep their GPU contexts + pinned pipes from one video to the next
       std::vector<std::unique_ptr<GpuBackend>> pool;
       for (int i = 0; i < threads_per_stream; ++i) pool.emplace_back(new GpuBackend());
+      struct AtExit {                                      // every way out of the loop reports what this stream held
+        std::vector<std::unique_ptr<GpuBackend>> &pool; std::mutex &mu; BatchSummary &sum;
+        ~AtExit() { std::lock_guard<std::mutex> l(mu); for (auto &b : pool) sum.held.add(b->resources()); }
+      } at_exit{pool, s_mu, sum};
       for (;;) {
         size_t idx;
         { std::lock_guard<std::mutex> l(q_mu); if (next >= files.size()) return; idx = next++; }   // get_next_file
@@ -606,6 +664,14 @@ int process_batch(const std::vector<std::string> &files, const std::string &outp
         } catch (const std::exception &e) {
           job.result.error = e.what();
         }
+        for (auto &b : pool) b->trim();                      // scratch of this video goes back to the device
+        {
+          std::lock_guard<std::mutex> l(s_mu);
+          const PipelineResult &r = job.result;
+          sum.frames_scanned += r.frames_scanned;
+          sum.init_us += r.init_us; sum.decode_us += r.decode_us; sum.analyze_us += r.analyze_us;
+          sum.copy_us += r.copy_us; sum.submit_us += r.submit_us; sum.wait_us += r.wait_us;
+        }
         if (rc != 0) {
           ++failed;
           if (errors) { std::lock_guard<std::mutex> l(e_mu); errors->push_back(in + ": " + job.result.error); }
@@ -613,12 +679,17 @@ int process_batch(const std::vector<std::string> &files, const std::string &outp
         }
         if (job.result.merge.do_cut < 0) continue;           // "No motion found": nothing to cut
         job.segments = job.result.segments;
+        { std::lock_guard<std::mutex> l(s_mu); ++sum.jobs; }
         jobs.push(std::move(job));
       }
     });
   }
   for (auto &t : streams) t.join();
   jobs.finish();
+  sum.failed = (size_t)failed.load();
+  sum.wall_us = (long)std::chrono::duration_cast<std::chrono::microseconds>(
+                    std::chrono::high_resolution_clock::now() - wall0).count();
+  if (summary) *summary = sum;
   return failed.load();
 }
 

@@ -1,11 +1,13 @@
 // mtgpu_scan_file — the scan + merge half of `motion_trim` on the GPU, reading extracted motion
 // vectors from .mtmv containers instead of decoding with FFmpeg:
-//   mtgpu_scan_file stream.mtmv [more.mtmv ...] [--threads T] [--streams S] [--outdir DIR] [--timestamps]
+//   mtgpu_scan_file stream.mtmv [more.mtmv ...] [--threads T] [--streams S] [--outdir DIR] [--timestamps] [--summary]
 // One file: like `motion_trim in out` (single ProcessingPipeline).  Several files: like
 // `motion_trim in_dir out_dir` (BatchProcessor): S streams x T workers, jobs consumed by one
 // thread (here: printed).  Configuration comes from the same environment variables as the
 // reference (MV_THRESHOLD_SQ, VECTORS_NEEDED, CHUNK_DURATION_SEC, TARGET_FPS, ...).
 // Prints one JSON object per input with a job: the FFmpegJob segment list (%.17g) + merge result.
+// --summary (several files): one more line {"batch_summary": ...} — frames scanned, wall time, worker-time
+// breakdown and what the S x T workers held (contexts, pipes, HIP streams, pinned / device bytes).
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -57,14 +59,16 @@ class RepeatSource : public FrameSource {
   }
 };
 
+static bool g_summary = false;    // --summary
 static bool g_print_ts = false;   // --timestamps: also print the pooled motion timestamps, sorted (%.17g)
 
 static void print_job(const std::string &input, const PipelineResult &r, const std::vector<mt_segment> &segs) {
-  std::printf("{\"input\": \"%s\", \"chunks\": %d, \"threads\": %d, \"motion_frames\": %zu, \"n_timestamps\": %llu, "
+  std::printf("{\"input\": \"%s\", \"chunks\": %d, \"threads\": %d, \"frames_scanned\": %llu, \"motion_frames\": %zu, \"n_timestamps\": %llu, "
               "\"do_cut\": %d, \"time_removed\": %.17g, \"saved_pct\": %.17g, \"seek_us\": %ld, "
               "\"decode_us\": %ld, \"analyze_us\": %ld, \"init_us\": %ld, \"scan_wall_us\": %ld, \"scan_work_us\": %ld, "
               "\"copy_us\": %ld, \"submit_us\": %ld, \"wait_us\": %ld, \"segments\": [",
-              input.c_str(), r.chunks, r.threads, r.motion_frames, (unsigned long long)r.merge.n_timestamps,
+              input.c_str(), r.chunks, r.threads, (unsigned long long)r.frames_scanned, r.motion_frames,
+              (unsigned long long)r.merge.n_timestamps,
               r.merge.do_cut, r.merge.time_removed, r.merge.saved_pct, r.seek_us, r.decode_us, r.analyze_us, r.init_us,
               r.scan_wall_us, r.scan_work_us, r.copy_us, r.submit_us, r.wait_us);
   for (size_t i = 0; i < segs.size(); ++i)
@@ -91,6 +95,7 @@ int main(int argc, char **argv) {
     else if (!std::strcmp(argv[i], "--streams") && i + 1 < argc) streams = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--outdir") && i + 1 < argc) outdir = argv[++i];
     else if (!std::strcmp(argv[i], "--timestamps")) g_print_ts = true;
+    else if (!std::strcmp(argv[i], "--summary")) g_summary = true;
     else if (!std::strcmp(argv[i], "--repeat") && i + 1 < argc) repeat = std::atol(argv[++i]);
     else files.push_back(argv[i]);
   }
@@ -114,17 +119,37 @@ int main(int argc, char **argv) {
     std::mutex mm;
     std::map<std::string, std::shared_ptr<MtmvFile>> open_files;
     auto open_source = [&](const std::string &path) {
-      std::shared_ptr<MtmvFile> f;
-      { std::lock_guard<std::mutex> l(mm); f = open_files[path] = std::make_shared<MtmvFile>(path); }
-      return [f] { return std::unique_ptr<FrameSource>(new MtmvSource(*f)); };
+      std::shared_ptr<MtmvFile> f = std::make_shared<MtmvFile>(path);   // mapped (and pre-faulted) outside the lock:
+      { std::lock_guard<std::mutex> l(mm); open_files[path] = f; }       // 64 streams open their files concurrently
+      return [f, repeat]() -> std::unique_ptr<FrameSource> {
+        if (repeat > 1) return std::unique_ptr<FrameSource>(new RepeatSource(*f, (uint64_t)repeat));
+        return std::unique_ptr<FrameSource>(new MtmvSource(*f));
+      };
     };
     JobQueue jobs;
     std::vector<std::string> errors;
     int failed = 0;
-    std::thread producer([&] { failed = process_batch(files, outdir, streams, threads, open_source, jobs, &errors); });
+    BatchSummary sum;
+    std::thread producer([&] { failed = process_batch(files, outdir, streams, threads, open_source, jobs, &errors, &sum); });
     ScanJob job;                                   // the single consumer (batch_processor.cpp:138-150)
     while (jobs.pop(job)) print_job(job.input_path, job.result, job.segments);
     producer.join();
+    if (g_summary) {
+      const Resources &h = sum.held;
+      std::printf("{\"batch_summary\": {\"streams\": %d, \"threads_per_stream\": %d, \"videos\": %zu, \"jobs\": %zu, "
+                  "\"failed\": %zu, \"frames_scanned\": %llu, \"wall_us\": %ld, \"init_us\": %ld, \"decode_us\": %ld, "
+                  "\"analyze_us\": %ld, \"copy_us\": %ld, \"submit_us\": %ld, \"wait_us\": %ld, "
+                  "\"held\": {\"contexts\": %llu, \"pipes\": %llu, \"hip_streams\": %llu, \"hip_events\": %llu, "
+                  "\"mem_pools\": %llu, \"pinned_bytes\": %llu, \"device_bytes\": %llu, \"scratch_pool_high_bytes\": %llu, "
+                  "\"submits\": %llu}}}\n",
+                  sum.streams, sum.threads_per_stream, sum.videos, sum.jobs, sum.failed,
+                  (unsigned long long)sum.frames_scanned, sum.wall_us, sum.init_us, sum.decode_us, sum.analyze_us,
+                  sum.copy_us, sum.submit_us, sum.wait_us, (unsigned long long)h.contexts, (unsigned long long)h.pipes,
+                  (unsigned long long)h.hip_streams, (unsigned long long)h.hip_events, (unsigned long long)h.mem_pools,
+                  (unsigned long long)h.pinned_bytes, (unsigned long long)h.device_bytes,
+                  (unsigned long long)h.pool_reserved_high, (unsigned long long)h.submits);
+      std::fflush(stdout);
+    }
     for (auto &e : errors) std::fprintf(stderr, "error: %s\n", e.c_str());
     return failed ? 1 : 0;
   } catch (const std::exception &e) {

@@ -476,6 +476,30 @@ void mtgpu_destroy(mtgpu_ctx *c) {
   delete c;
 }
 
+int mtgpu_get_stats(mtgpu_ctx *c, mtgpu_ctx_stats *out) {
+  if (!c || !out) return fail(MT_ERR_INVALID, "NULL argument");
+  std::memset(out, 0, sizeof *out);
+  std::lock_guard<std::mutex> lock(c->mu);
+  out->staging_device_bytes = c->d_mv.cap + c->d_off.cap + c->d_sd.cap + c->d_flags.cap + c->d_misc.cap;
+  out->hip_streams = c->stream ? 1u : 0u;
+  out->private_pool = c->pool ? 1u : 0u;
+  if (c->pool) {
+    uint64_t cur = 0, high = 0;
+    HIP_TRY(hipMemPoolGetAttribute(c->pool, hipMemPoolAttrReservedMemCurrent, &cur));
+    HIP_TRY(hipMemPoolGetAttribute(c->pool, hipMemPoolAttrReservedMemHigh, &high));
+    out->pool_reserved_bytes = cur;
+    out->pool_reserved_high = high;
+  }
+  return MT_OK;
+}
+
+int mtgpu_trim(mtgpu_ctx *c) {
+  if (!c) return fail(MT_ERR_INVALID, "ctx is NULL");
+  HIP_TRY(hipSetDevice(c->device));
+  if (c->pool) HIP_TRY(hipMemPoolTrimTo(c->pool, 0));
+  return MT_OK;
+}
+
 int mtgpu_get_params(const mtgpu_ctx *c, mt_scan_params *out) {
   if (!c || !out) return fail(MT_ERR_INVALID, "NULL argument");
   *out = c->params;

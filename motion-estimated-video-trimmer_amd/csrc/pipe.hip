@@ -49,6 +49,7 @@ struct mtgpu_batch {
   uint8_t *d_sd = nullptr;
   uint8_t *d_flags = nullptr;
   size_t hdr_bytes = 0;
+  size_t stage_bytes = 0;             // size of h_stage (and of d_stage when it exists)
   uint64_t cap_records = 0, n_records = 0;
   uint32_t cap_frames = 0, n_frames = 0;
   int rec_bytes = MT_COMPACT_BYTES;   // bytes per staged record: 8 (compact) or 40 (AoS)
@@ -119,6 +120,7 @@ int alloc_records(mtgpu_batch *b, uint64_t records, bool inject_failure = false)
   b->h_stage = h_new;
   b->d_stage = d_new;
   b->hdr_bytes = hdr;
+  b->stage_bytes = bytes;
   b->h_off = reinterpret_cast<uint64_t *>(b->h_stage);
   b->h_sd = b->h_stage + sizeof(uint64_t) * (nf + 1);
   b->h_mv = b->h_stage + b->hdr_bytes;
@@ -323,6 +325,21 @@ int mtgpu_pipe_collect(mtgpu_pipe *p, mtgpu_batch **out, const uint8_t **flags, 
   if (pts) *pts = b->h_pts;
   if (tags) *tags = b->h_tag;
   if (n_frames) *n_frames = b->n_frames;
+  return MT_OK;
+}
+
+int mtgpu_pipe_get_stats(mtgpu_pipe *p, mtgpu_pipe_stats *out) {
+  if (!p || !out) return fail(MT_ERR_INVALID, "NULL argument");
+  std::lock_guard<std::mutex> lock(p->mu);
+  std::memset(out, 0, sizeof *out);
+  for (const mtgpu_batch *b : p->bufs) {
+    const size_t nf = (size_t)b->cap_frames + 1;
+    out->pinned_bytes += b->stage_bytes + nf * (sizeof(double) + sizeof(uint64_t) + 1);
+    if (!b->zero_copy) out->device_bytes += b->stage_bytes + nf;
+  }
+  out->submits = (uint64_t)p->submits;
+  out->n_buffers = (uint32_t)p->bufs.size();
+  out->layout = (p->rec_bytes == MT_MV_BYTES ? MT_LAYOUT_AOS40 : MT_LAYOUT_COMPACT8) | (p->zero_copy ? MT_LAYOUT_ZERO_COPY : 0);
   return MT_OK;
 }
 

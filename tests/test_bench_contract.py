@@ -57,8 +57,8 @@ def test_bench_gpus_n_launches_n_ranks_itself(tmp_path):
     started = []
 
     class FakeProc:
-        def __init__(self, cmd, env, stdout):
-            started.append((cmd, env, stdout))
+        def __init__(self, cmd, env, stdout, stderr=None):
+            started.append((cmd, env, stdout, getattr(stderr, "name", None)))
             self.rank = int(env["RANK"])
             self.code = None
             self.terminated = False
@@ -76,6 +76,9 @@ def test_bench_gpus_n_launches_n_ranks_itself(tmp_path):
     assert len(started) == 4
     assert all(c[0][1].endswith("bench.py") and c[0][2:] == argv for c in started)
     assert started[0][2] is None and all(c[2] == subprocess.DEVNULL for c in started[1:])   # rank 0's stdout is ours
+    # rank 0 keeps our stderr; every other rank's stderr is kept in its own file
+    assert started[0][3] is None
+    assert [os.path.basename(c[3]) for c in started[1:]] == [f"bench_rank{r}.err.stderr.log" for r in (1, 2, 3)]
     assert len({c[1]["MASTER_PORT"] for c in started}) == 1
     started.clear()
     fail_rank, fail_rank_code = 2, 7
@@ -89,8 +92,9 @@ def test_bench_gpus_n_launches_n_ranks_itself(tmp_path):
                      "sys.exit(3 if os.environ.get('FAIL_RANK') == str(r) else 0)\n")
     real_popen = subprocess.Popen
 
-    def probe_popen(cmd, env, stdout):
-        return real_popen([sys.executable, str(probe)], env=env, stdout=subprocess.PIPE if stdout is None else stdout)
+    def probe_popen(cmd, env, stdout, stderr=None):
+        return real_popen([sys.executable, str(probe)], env=env, stdout=subprocess.PIPE if stdout is None else stdout,
+                          stderr=stderr)
     assert bench.launch_ranks(bench.parse(["--gpus", "3"]), ["--gpus", "3"], environ=dict(os.environ), popen=probe_popen) == 0
     assert bench.launch_ranks(bench.parse(["--gpus", "3"]), ["--gpus", "3"],
                               environ=dict(os.environ, FAIL_RANK="1"), popen=probe_popen) == 3
