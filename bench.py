@@ -40,7 +40,9 @@ HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; ~6
 # "other_workloads" (north_star: frames/s on 1080p AND 4K; config 5 = the 960x540 fine grid).
 OTHER_WORKLOADS = [("4k_dense8x8", "code_defaults", 1024, 40),
                    ("4k_fine", "code_defaults", 1024, 12),
-                   ("4k_fine", "shipped_env", 1024, 12),
+                   # shipped env (VECTORS_NEEDED 4) on the fine grid needs >= 4 records per 4x4 block somewhere to
+                   # ever say yes: the dense4 density (4 per block inside moving regions, ragged frames)
+                   ("4k_fine_dense4", "shipped_env", 1024, 12),
                    # SURVEY.md 8(d) config 2, the other parameter set and the secondary density
                    # (one record per 16-px cell: 326 KB frames, several per workgroup)
                    ("1080p_dense8x8", "shipped_env", 4096, 40),
@@ -56,7 +58,7 @@ def parse(argv=None):
     ap.add_argument("--streams", type=int, default=8, help="streams per GPU (frames split evenly)")
     ap.add_argument("--distinct", type=int, default=60, help="distinct generated frames per GPU (tiled)")
     ap.add_argument("--workload", default="1080p_dense8x8",
-                    choices=["1080p_dense8x8", "1080p_dense16", "4k_dense8x8", "4k_fine"])
+                    choices=["1080p_dense8x8", "1080p_dense16", "4k_dense8x8", "4k_fine", "4k_fine_dense4"])
     ap.add_argument("--params", default="code_defaults", choices=["code_defaults", "shipped_env"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample budget (0 = skip)")
     ap.add_argument("--no-merge", action="store_true", help="time the scan kernel alone")
@@ -147,6 +149,8 @@ def make_spec(workload, seed):
         return synth.spec_1080p(seed=seed, sub=1), (1920, 1080, {})
     if workload == "4k_dense8x8":
         return synth.spec_4k(seed=seed, sub=2), (3840, 2160, {})
+    if workload == "4k_fine_dense4":
+        return synth.spec_4k_fine_dense(seed=seed), (3840, 2160, dict(block_size=4, block_shift=2))
     return synth.spec_4k_fine(seed=seed), (3840, 2160, dict(block_size=4, block_shift=2))
 
 
@@ -347,6 +351,8 @@ def other_workloads(dev, distinct):
         assert np.array_equal(flags, np.tile(tile, w["reps"])[:frames]), f"{wl}: flags are not tile-periodic"
         want = ob.scan_frames(w["params"], w["mv"], w["off"], None, nthreads=min(len(os.sched_getaffinity(0)), 16))
         assert np.array_equal(tile, want), f"{wl}: GPU flags differ from the oracle"
+        # a leg whose answer is constant times nothing but the stream: every leg must say yes AND no
+        assert 0 < int(flags.sum()) < frames, f"{wl}/{pn}: degenerate workload ({int(flags.sum())} motion frames of {frames})"
         r = roofline_of(w["alg_bytes"], kern_ms)
         p = w["params"]
         out.append({"workload": f"synthetic {wl} MV arrays, {p.grid_w}x{p.grid_h} grid, {frames} frames "

@@ -120,7 +120,9 @@ typedef struct mt_merge_result {
                            * 0: full copy {0,duration} (pipeline.cpp:358, 387-388);          *
                            * -1: no motion, run() returns before any job (308-319)           */
   int32_t status;         /* MT_OK, or MT_ERR_INVALID if a timestamp was NaN (device merges     *
-                           * report per-stream problems here)                                */
+                           * report per-stream problems here); every other field is then 0   *
+                           * and do_cut -1, whatever the list length (std::sort of NaN is    *
+                           * undefined in the reference: outside the defined domain)         */
 } mt_merge_result;
 
 /* Status codes shared by both libraries (0 = ok; the reference itself only

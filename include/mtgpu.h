@@ -252,7 +252,10 @@ int mtgpu_pipe_submit(mtgpu_pipe *pipe, mtgpu_batch *batch);
 
 /* Block until the OLDEST submitted batch is done and expose its results (host pointers valid
  * until mtgpu_pipe_release).  MT_ERR_INVALID if nothing is in flight.  If waiting fails, *out
- * is still set so that the batch can be released. */
+ * is still set so that the batch can be released — its results are lost, but its stream has been
+ * drained first, so the staging may be refilled at once (with zero-copy staging the kernel reads
+ * that pinned memory itself).  If even the drain fails the batch is retired: release accepts it,
+ * acquire never returns it again, and only mtgpu_pipe_destroy frees it. */
 int mtgpu_pipe_collect(mtgpu_pipe *pipe, mtgpu_batch **out, const uint8_t **flags,
                        const double **pts, const uint64_t **tags, uint32_t *n_frames);
 int mtgpu_pipe_release(mtgpu_pipe *pipe, mtgpu_batch *batch);

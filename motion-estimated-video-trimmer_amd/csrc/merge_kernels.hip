@@ -133,7 +133,8 @@ __global__ __launch_bounds__(MB) void merge_streams_kernel(
   const unsigned int cond = sh.cond;
   if (cond & 1u) {  // NaN timestamp: outside the defined domain
     if (tid == 0) {
-      res->n_timestamps = M; res->n_segments = 0; res->time_removed = 0.0; res->saved_pct = 0.0;
+      // same answer as the multi-workgroup path (ml_result): nothing of a NaN list is reported
+      res->n_timestamps = 0; res->n_segments = 0; res->time_removed = 0.0; res->saved_pct = 0.0;
       res->do_cut = -1; res->status = MT_ERR_INVALID;
     }
     return;

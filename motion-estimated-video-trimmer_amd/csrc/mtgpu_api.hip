@@ -76,7 +76,7 @@ struct mtgpu_ctx {
   int variant = 0;       // MTGPU_VARIANT experiment knob
   int slices_request = 0;  // 0 = auto, else 1/2/4/8 (mtgpu_set_slices, MTGPU_FORCE_SLICES)
   int wide_chunk_rows = 0, wide_lds_bytes = 0;   // single-workgroup-per-CU layout (see make_plan)
-  int item_chunk = 0;    // MTGPU_ITEM_CHUNK (tests): work items per kernel launch, 0 = 2^30
+  int item_chunk = 0;    // MTGPU_ITEM_CHUNK (tests): workgroups per kernel launch, 0 = 2^30
   int lds_max = 0;       // device limit of LDS per workgroup
   int group_request = 0; // MTGPU_GROUP: frames per workgroup, 0 = automatic
   int min_lds_kb = 0;    // MTGPU_MIN_LDS_KB: launch with at least this much LDS (caps workgroups per CU), 0 = automatic
@@ -327,6 +327,8 @@ int launch_scan_on(mtgpu_ctx *c, const void *d_mv, uint64_t n_records, const uin
   L.k = c->k;
   L.k.slices = choose_slices(c, n_records, n_frames);
   L.k.group = choose_group(c, n_records, n_frames, rec_bytes, L.k.slices);
+  if ((uint64_t)n_frames * (uint64_t)L.k.slices >= (1ull << 32))
+    return fail(MT_ERR_INVALID, "%u frames x %d slices: work items must stay below 2^32 per call", n_frames, L.k.slices);
   L.block = c->plan.block_threads;
   L.variant = c->variant;
   L.item_chunk = (unsigned long long)c->item_chunk;

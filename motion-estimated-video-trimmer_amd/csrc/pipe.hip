@@ -16,8 +16,12 @@
 //
 // Batch states: 0 free -> (acquire) 1 filling -> (submit) 2 in flight -> (collect) 3 collected
 // -> (release) 0.  A failed submit drains the batch's stream and leaves it in state 1 with its
-// contents intact (retry or release); a failed collect still hands the batch out (state 3) so
-// that it can be released: an error never strands a staging buffer.
+// contents intact (retry or release).  A failed collect (the wait on the batch's event failed)
+// first drains the batch's STREAM — with zero-copy staging the kernel reads h_stage and writes
+// h_flags over PCIe, so the pinned block must not be refilled or freed while it may still run —
+// and then hands the batch out (state 3) so that it can be released.  If even that drain fails
+// the batch is POISONED (state 4): release accepts it, acquire never hands it out again, and
+// only mtgpu_pipe_destroy touches its memory.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -56,7 +60,7 @@ struct mtgpu_batch {
   bool zero_copy = false;             // the scan reads the pinned staging (and writes the flags) over PCIe itself
   hipStream_t stream = nullptr;
   hipEvent_t done = nullptr;
-  int state = 0;   // 0 free, 1 filling, 2 in flight, 3 collected
+  int state = 0;   // 0 free, 1 filling, 2 in flight, 3 collected, 4 poisoned (never reused)
   mtgpu_pipe *owner = nullptr;
 };
 
@@ -65,6 +69,9 @@ struct mtgpu_pipe {
   int rec_bytes = MT_COMPACT_BYTES;
   bool zero_copy = false;
   long inject_submit_fail = 0;   // MTGPU_INJECT_SUBMIT_FAIL=k (tests): the k-th submit fails after its copies were queued
+  long inject_collect_fail = 0;  // MTGPU_INJECT_COLLECT_FAIL=k (tests): the k-th collect's event wait "fails";
+                                 // negative: its stream drain "fails" as well (the batch is poisoned)
+  long collects = 0;
   long submits = 0;
   bool inject_grow_fail = false; // MTGPU_INJECT_GROW_FAIL=1 (tests): growing a batch for an oversize frame fails
   std::vector<mtgpu_batch *> bufs;
@@ -198,6 +205,7 @@ int mtgpu_pipe_create_layout(mtgpu_ctx *ctx, uint64_t max_records_per_batch, uin
   p->zero_copy = (layout & MT_LAYOUT_ZERO_COPY) != 0;
   if (const char *v = std::getenv("MTGPU_INJECT_SUBMIT_FAIL")) p->inject_submit_fail = std::atol(v);
   if (const char *v = std::getenv("MTGPU_INJECT_GROW_FAIL")) p->inject_grow_fail = std::atol(v) != 0;
+  if (const char *v = std::getenv("MTGPU_INJECT_COLLECT_FAIL")) p->inject_collect_fail = std::atol(v);
   for (int i = 0; i < n_buffers; ++i) {
     mtgpu_batch *b = nullptr;
     int rc = alloc_batch(&b, max_records_per_batch, max_frames_per_batch, p->rec_bytes, p->zero_copy);
@@ -229,6 +237,10 @@ int mtgpu_pipe_acquire(mtgpu_pipe *p, mtgpu_batch **out) {
       return MT_OK;
     }
   *out = nullptr;
+  size_t retired = 0;
+  for (const mtgpu_batch *b : p->bufs) retired += b->state == 4;
+  if (retired == p->bufs.size())
+    return fail(MT_ERR_DEVICE, "every staging batch of this pipe was retired after a failed collect: destroy the pipe");
   return fail(MT_ERR_BUSY, "all %zu staging batches are in flight or held: collect and release one", p->bufs.size());
 }
 
@@ -318,9 +330,25 @@ int mtgpu_pipe_collect(mtgpu_pipe *p, mtgpu_batch **out, const uint8_t **flags, 
     p->inflight.pop_front();
     b->state = 3;
   }
+  long nth;
+  { std::lock_guard<std::mutex> lock(p->mu); nth = ++p->collects; }
   *out = b;                       // handed out even on failure, so that it can be released
   hipError_t e = hipEventSynchronize(b->done);
-  if (e != hipSuccess) return hip_fail(e, "hipEventSynchronize");
+  const bool inject = p->inject_collect_fail != 0 && nth == std::labs(p->inject_collect_fail);
+  if (inject && e == hipSuccess) e = hipErrorUnknown;
+  if (e != hipSuccess) {
+    // The kernel of this batch may still be running: nobody may refill (or free) its pinned staging
+    // until the batch's stream has drained.  If the drain fails too, the batch is never reused.
+    hipError_t e2 = hipStreamSynchronize(b->stream);
+    if (inject) e2 = p->inject_collect_fail < 0 ? hipErrorUnknown : e2;
+    if (e2 != hipSuccess) {
+      std::lock_guard<std::mutex> lock(p->mu);
+      b->state = 4;
+      return fail(MT_ERR_DEVICE, "hipEventSynchronize: %s; draining the batch's stream failed too (%s): "
+                  "the batch is retired", hipGetErrorString(e), hipGetErrorString(e2));
+    }
+    return hip_fail(e, inject ? "hipEventSynchronize (injected, MTGPU_INJECT_COLLECT_FAIL)" : "hipEventSynchronize");
+  }
   if (flags) *flags = b->h_flags;
   if (pts) *pts = b->h_pts;
   if (tags) *tags = b->h_tag;
@@ -346,6 +374,7 @@ int mtgpu_pipe_get_stats(mtgpu_pipe *p, mtgpu_pipe_stats *out) {
 int mtgpu_pipe_release(mtgpu_pipe *p, mtgpu_batch *b) {
   if (!p || !b || b->owner != p) return fail(MT_ERR_INVALID, "batch does not belong to this pipe");
   std::lock_guard<std::mutex> lock(p->mu);
+  if (b->state == 4) return MT_OK;        // poisoned by a failed collect: stays out of circulation
   if (b->state != 3 && b->state != 1) return fail(MT_ERR_INVALID, "batch is in flight");
   b->state = 0;
   return MT_OK;

@@ -41,7 +41,7 @@ struct ScanLaunch {
   ScanK k;
   int block;
   int variant;             // experiment knob (MTGPU_VARIANT), 0 = shipped kernel
-  unsigned long long item_chunk;  // work items per launch (0 = 2^30; MTGPU_ITEM_CHUNK shrinks it for tests)
+  unsigned long long item_chunk;  // WORKGROUPS per launch (0 = 2^30; MTGPU_ITEM_CHUNK shrinks it for tests); a workgroup scans k.group items
   int lds_bytes;
   int lds_max;             // device limit of dynamic LDS per workgroup (set once per kernel instantiation)
   int device;

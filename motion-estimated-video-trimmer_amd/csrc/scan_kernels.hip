@@ -724,6 +724,9 @@ hipError_t launch_scan(const ScanLaunch &L) {
   if (L.rec_bytes != 40 && L.rec_bytes != 8) return hipErrorInvalidValue;
   hipError_t e;
   if (L.k.bands > 1 && (L.k.slices != 1 || !L.spill_q)) return hipErrorInvalidValue;
+  // work items (frames x slices) are 32-bit inside the kernel (item0 + blockIdx.x * group)
+  if ((unsigned long long)L.n_frames * (unsigned long long)(L.k.slices > 0 ? L.k.slices : 1) >= (1ull << 32))
+    return hipErrorInvalidValue;
   if (L.k.slices > 1) {
     if (!L.slice_ws || !L.tickets) return hipErrorInvalidValue;
     e = hipMemsetAsync(L.tickets, 0, sizeof(unsigned int) * (size_t)L.n_frames, L.stream);

@@ -63,6 +63,11 @@ class StreamSpec:
     salt_p: float = 1e-3       # isolated noisy cells per cell per frame
     oob_p: float = 1e-3        # records whose dst lies outside the frame
     events: List[Event] = field(default_factory=list)
+    # records per cell INSIDE event rectangles and salt cells (sub == 1 only): a moving region of real footage is
+    # coded with more partitions and two prediction directions, so a fine-grid cell there carries several MVs.
+    # 4 = two directions (source -1 / +1) x two partitions: the only way a one-record-per-4x4-block stream can
+    # reach VECTORS_NEEDED = 4 of the shipped env (config/motion_trim.env:75).  Frames then differ in size.
+    event_records: int = 1
 
     @property
     def cells_x(self) -> int:
@@ -95,6 +100,15 @@ def spec_4k(seed=1, sub=2, **kw) -> StreamSpec:
 def spec_4k_fine(seed=1, **kw) -> StreamSpec:
     """HEVC-style 4x4 MV granularity: one record per 4x4 block (960x540 grid)."""
     return StreamSpec(3840, 2160, 4, 1, seed=seed, **kw)
+
+
+def spec_4k_fine_dense(seed=1, **kw) -> StreamSpec:
+    """The same grid with 4 records per 4x4 block inside moving regions (2 directions x 2 partitions):
+    the density at which the shipped env's VECTORS_NEEDED = 4 can say yes AND no on this grid.
+    Salt cells carry 4 records too (an ACTIVE cell without an active neighbour must not trigger); their rate
+    is lowered to ~10 per frame so that two of them are practically never adjacent on 518 400 cells."""
+    kw.setdefault("salt_p", 2e-5)
+    return StreamSpec(3840, 2160, 4, 1, seed=seed, event_records=4, **kw)
 
 
 def scripted_events(spec: StreamSpec, n_frames: int, seed: Optional[int] = None) -> List[Event]:
@@ -158,8 +172,27 @@ def gen_frame(spec: StreamSpec, f: int) -> Optional[np.ndarray]:
     big = np.where(oob, 9, 0)                            # and they do move (mag above threshold)
     dx = np.where(oob, big, dx)
 
+    source = np.full(n, -1, dtype=np.int64)
+    if spec.event_records > 1 and sub == 1:
+        # cells of moving regions (events, salt) carry event_records records, in place (raster order kept):
+        # record j of such a cell has direction -1 / +1 alternating and sits in partition j // 2 of the cell
+        busy = salt.copy()
+        for e in spec.events:
+            if e.f0 <= f < e.f1:
+                drift = ((f - e.f0) * e.dx) // (4 * blk)
+                busy |= (mx >= e.cx + drift) & (mx < e.cx + drift + e.cw) & (my >= e.cy) & (my < e.cy + e.ch)
+        busy &= ~oob
+        counts = np.where(busy, spec.event_records, 1)
+        idx = np.repeat(r, counts)
+        j = np.arange(len(idx), dtype=np.int64) - np.repeat(np.cumsum(counts) - counts, counts)
+        dst_x, dst_y, dx, dy, source = dst_x[idx], dst_y[idx], dx[idx], dy[idx], source[idx]
+        multi = busy[idx]
+        source = np.where(multi & (j % 2 == 1), 1, source)
+        dst_x = np.where(multi, mx[idx] * blk + ((j // 2) * 2 + 1) % blk, dst_x)
+        n = len(idx)
+
     out = np.zeros(n, dtype=MV_DTYPE)
-    out["source"] = -1
+    out["source"] = source.astype(np.int32)
     out["w"] = part
     out["h"] = part
     out["dst_x"] = dst_x.astype(np.int16)

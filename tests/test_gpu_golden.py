@@ -530,6 +530,52 @@ def test_pipe_submit_failure_leaves_batches_usable(gpu_scanner_factory, monkeypa
     pipe.close()
 
 
+@pytest.mark.parametrize("poison", [False, True])
+def test_pipe_collect_failure_never_frees_a_running_batch(gpu_scanner_factory, monkeypatch, poison):
+    """a failed wait in mtgpu_pipe_collect used to hand the batch out while its zero-copy kernel
+    could still be reading the pinned staging.  Now the collect drains the batch's stream first
+    (MTGPU_INJECT_COLLECT_FAIL=2: the 2nd collect's wait fails); if that drain fails as well (=-2) the batch is
+    retired: release accepts it, acquire never returns it, the pipe keeps working on the remaining batch."""
+    import ctypes as C
+    spec = synth.spec_1080p(seed=31, sub=1)
+    spec.events = synth.scripted_events(spec, 48)
+    frames = [synth.gen_frame(spec, i) for i in range(48)]
+    p = ob.params_from_config(1920, 1080, vectors_needed=1)
+    s = gpu_scanner_factory(m.ScanParams.from_config(1920, 1080, vectors_needed=1))
+    b = m.FrameBatch.from_frames(frames)
+    want = ob.scan_frames(p, b.mv, b.frame_off, b.has_sd)
+    monkeypatch.setenv("MTGPU_INJECT_COLLECT_FAIL", "-2" if poison else "2")
+    pipe = m.ScanPipe(s, 8160 * 4, 4, 2)
+    monkeypatch.delenv("MTGPU_INJECT_COLLECT_FAIL")
+    lib = m.load_library()
+    failures = 0
+    for i, f in enumerate(frames):
+        try:
+            pipe.feed(f, spec.pts_seconds(i), tag=i)
+        except m.MtgpuError as e:
+            assert e.code == 3 and ("retired" in str(e) if poison else "injected" in str(e))
+            failures += 1
+            pipe.feed(f, spec.pts_seconds(i), tag=i)       # the wrapper gave the failed batch back: carry on
+    assert failures == 1
+    out = pipe.drain()
+    tags = [t for _, _, t in out]
+    lost = sorted(set(range(48)) - set(tags))
+    assert len(lost) == 4 and lost == list(range(lost[0], lost[0] + 4))      # exactly the failed batch's frames
+    assert tags == sorted(tags) and [fl for _, fl, _ in out] == want[tags].tolist()
+    held = []
+    for _ in range(1 if poison else 2):
+        h = C.c_void_p()
+        m._abi.check(lib.mtgpu_pipe_acquire(pipe._pipe, C.byref(h)))
+        held.append(h)
+    assert lib.mtgpu_pipe_acquire(pipe._pipe, C.byref(C.c_void_p())) == m._abi.MT_ERR_BUSY
+    for h in held:
+        m._abi.check(lib.mtgpu_pipe_release(pipe._pipe, h))
+    st = m._abi.PipeStatsC()
+    m._abi.check(lib.mtgpu_pipe_get_stats(pipe._pipe, C.byref(st)))
+    assert st.n_buffers == 2 and st.device_bytes == 0 and st.pinned_bytes >= 2 * 8160 * 4 * 8
+    pipe.close()
+
+
 @pytest.mark.parametrize("layout", ["compact_zc", "aos_copy"])
 def test_pipe_growth_failure_keeps_the_batch_usable(gpu_scanner_factory, monkeypatch, layout):
     """A frame larger than a whole batch makes the pipe grow an empty batch; when that allocation fails
@@ -661,6 +707,17 @@ def test_merge_large_path_edge_sizes(gpu_scanner_factory, monkeypatch, job):
     with pytest.raises(m.MtgpuError) as ei:
         s.merge_segments(np.r_[rng.rand(3000), float("nan"), rng.rand(3000)], mps[0], job)
     assert ei.value.code == 1
+    # NaN through the device entry point: the same result record from the multi-workgroup path (forced on here)
+    # and from the one-workgroup kernel (a fresh context without the override) — ADVICE r2
+    import torch
+    bad = torch.tensor([3.0, float("nan"), 1.0, 2.0], dtype=torch.float64, device="cuda:0")
+    recs = []
+    for scanner in (s, gpu_scanner_factory(s.params)):
+        _, res = scanner.merge_timestamps_device(bad, mps[0], job)
+        torch.cuda.synchronize()
+        recs.append(m.results_from_bytes(res.cpu().numpy().reshape(1, -1))[0])
+    assert recs[0].tobytes() == recs[1].tobytes()
+    assert recs[0]["status"] == 1 and recs[0]["n_timestamps"] == 0 and recs[0]["do_cut"] == -1
     with pytest.raises(m.MtgpuError) as ei:                      # capacity: need reported, like the small path
         s.merge_segments(np.arange(6000.0) * 10.0, mps[0], False, cap=10)
     assert ei.value.code == 2

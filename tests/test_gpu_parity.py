@@ -119,6 +119,102 @@ def test_fine_grid_cluster_across_seams(gpu_scanner_factory, force_fb):
     assert list(want) == [1, 1, 1, 0]
 
 
+def _fine_shipped_env_scanner(gpu_scanner_factory):
+    kw = dict(m.config.SHIPPED_ENV)
+    kw.update(block_size=4, block_shift=2)
+    p = ob.params_from_config(3840, 2160, **kw)
+    assert (p.grid_w, p.grid_h, p.vertical_margin, p.vectors_needed, p.clusters_needed) == (960, 540, 27, 4, 2)
+    s = gpu_scanner_factory(p)
+    plan = s.plan                                   # the AUTOMATIC plan: 4-bit thermometer fields, 2 spill bands
+    assert (plan["counter_bits"], plan["counter_mode"], plan["bands"], plan["band_rows"]) == (4, 1, 2, 243)
+    return p, s
+
+
+def test_fine_grid_shipped_env_dense_stream_two_bands(gpu_scanner_factory):
+    """BASELINE config 5 under the SHIPPED env (config/motion_trim.env:36,75: T=4, VECTORS_NEEDED=4) on input
+    where that setting can say yes and no: 4 records per 4x4 block inside moving regions (2 directions x 2
+    partitions; synth.spec_4k_fine_dense).  Events in band 0, in band 1 (every vote there arrives through the
+    spill queue) and across the seam at rows 269 | 270; a region with only 3 records per block must stay
+    inactive; full-size ragged frames; automatic 2-band plan."""
+    p, s = _fine_shipped_env_scanner(gpu_scanner_factory)
+    spec = synth.spec_4k_fine_dense(seed=11)
+    spec.events = [synth.Event(1, 2, 300, 100, 5, 4, 9, 3),        # frame 1: band 0 only
+                   synth.Event(2, 3, 640, 400, 4, 3, -7, 2),       # frame 2: band 1 only (replayed votes)
+                   synth.Event(3, 4, 500, 268, 3, 4, 6, 0),        # frame 3: rows 268..271, across the seam
+                   synth.Event(4, 5, 10, 269, 1, 2, 5, 0),         # frame 4: ONE column, rows 269 + 270: exactly 2 centres
+                   synth.Event(5, 6, 700, 27, 6, 1, 8, 0),         # frame 5: a single row at y_min (horizontal pairs)
+                   synth.Event(6, 7, 100, 512, 2, 1, 8, 0)]        # frame 6: last analysed row, band 1
+    mv, off, pts, sd = synth.gen_stream(spec, 9)                   # frames 7, 8: no event (salt only) -> 0
+    counts = np.diff(off.astype(np.int64))
+    assert counts[0] == 0 and len(set(counts[1:].tolist())) > 3    # I-frame + ragged P-frames
+    want = assert_scan_parity(s, p, mv, off, sd)
+    assert want.tolist() == [0, 1, 1, 1, 1, 1, 1, 0, 0]
+    # the same frames with ONE record of every busy block removed (3 votes < VECTORS_NEEDED): nothing fires
+    keep = np.ones(len(mv), dtype=bool)
+    cell = (mv["dst_y"].astype(np.int64) >> 2) * 960 + (mv["dst_x"].astype(np.int64) >> 2)
+    for f in range(1, 9):
+        a, b = int(off[f]), int(off[f + 1])
+        c = cell[a:b]
+        dup = np.flatnonzero((c[1:] == c[:-1]) & (mv["source"][a + 1:b] == 1) & (mv["source"][a:b - 1] == -1)) + 1
+        first_of_four = dup[::2]                                    # records 1 and 3 of a block are "+1": drop record 1
+        keep[a + first_of_four] = False
+    mv3 = mv[keep]
+    off3 = np.concatenate([[0], np.cumsum([keep[int(off[f]):int(off[f + 1])].sum() for f in range(9)])]).astype(np.uint64)
+    assert (off[-1] - off3[-1]) >= 60
+    want3 = assert_scan_parity(s, p, mv3, off3, sd)
+    assert want3.sum() == 0
+
+
+def test_band_seam_cluster_needs_every_replayed_vote(gpu_scanner_factory):
+    """Hand-built frames on the automatic 2-band plan (centres [27,270) | [270,513), queue from row 269 on):
+    a vertical pair (x,269)+(x,270) has exactly CLUSTERS_NEEDED = 2 centres, one counted by each band, and
+    every cell holds exactly VECTORS_NEEDED = 4 votes — band 0 sees row 270 only as its halo, band 1 sees
+    row 269 only through replayed queue entries.  One vote fewer anywhere, or one lost replay, flips the flag."""
+    p, s = _fine_shipped_env_scanner(gpu_scanner_factory)
+
+    def frame(cells, filler=20000):
+        """cells: [(gx, gy, votes)]; `filler` still records around them so that the votes sit deep inside a
+        large frame (many streaming steps, many waves appending to the queue)."""
+        rng = np.random.RandomState(len(cells) * 7 + cells[0][1])
+        recs = []
+        for gx, gy, votes in cells:
+            recs += [(gx * 4 + 1 + (i & 1) * 2, gy * 4 + 2, 3) for i in range(votes)]
+        n = filler + len(recs)
+        mv = np.zeros(n, dtype=m.MV_DTYPE)
+        mv["dst_x"] = rng.randint(0, 3840, size=n)
+        mv["dst_y"] = rng.randint(0, 2160, size=n)
+        mv["src_x"], mv["src_y"] = mv["dst_x"] - 1, mv["dst_y"]            # |d|^2 = 1 < 4: below the threshold
+        where = rng.choice(n, size=len(recs), replace=False)
+        for w, (x, y, d) in zip(where, recs):
+            mv["dst_x"][w], mv["dst_y"][w] = x, y
+            mv["src_x"][w], mv["src_y"][w] = x - d, y                      # |d|^2 = 9 >= 4
+        return mv
+
+    cases = [([(400, 269, 4), (400, 270, 4)], 1),        # the seam pair: 1 centre per band
+             ([(400, 269, 4), (400, 270, 3)], 0),        # row 270 one vote short: no cell has an active neighbour
+             ([(400, 269, 3), (400, 270, 4)], 0),        # row 269 one vote short (band 1's halo, replayed)
+             ([(400, 270, 4), (400, 271, 4)], 1),        # both in band 1: only replayed votes
+             ([(400, 270, 4), (400, 271, 3), (401, 270, 3)], 0),
+             ([(400, 268, 4), (400, 269, 4)], 1),        # both in band 0; row 269 is queued as well, harmlessly
+             ([(400, 269, 4), (401, 269, 4)], 1),        # horizontal pair on band 0's last centre row
+             ([(400, 270, 4), (401, 270, 4)], 1),        # horizontal pair on band 1's first centre row
+             ([(400, 269, 4), (401, 270, 4)], 0),        # diagonal across the seam: not 4-neighbours
+             ([(400, 269, 9), (400, 270, 200)], 1),      # saturated fields (thermometer full) on both sides
+             ([(0, 269, 4), (0, 270, 4), (959, 269, 4), (959, 270, 4)], 0),   # columns 0 / gw-1 are never centres
+             ([(1, 269, 4), (0, 269, 4), (958, 270, 4), (959, 270, 4)], 1)]   # ... but they count as neighbours
+    frames = [frame(c) for c, _ in cases]
+    b = m.FrameBatch.from_frames(frames)
+    want = assert_scan_parity(s, p, b.mv, b.frame_off, b.has_sd)
+    assert want.tolist() == [w for _, w in cases]
+    # and as 8-byte compact records through the pinned zero-copy pipe (what the host dispatcher stages)
+    pipe = m.ScanPipe(s, 3 * 20100, 3, 2)
+    for i, f in enumerate(frames):
+        pipe.feed(f, float(i), tag=i)
+    got8 = pipe.drain()
+    pipe.close()
+    assert [fl for _, fl, _ in got8] == want.tolist()
+
+
 @pytest.mark.parametrize("force_fb", [1, 2, 4, 8, 108])
 @pytest.mark.parametrize("vec", [1, 2, 3, 4, 5, 8, 9, 16, 255])
 def test_packed_counter_forms(gpu_scanner_factory, force_fb, vec):
