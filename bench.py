@@ -270,7 +270,7 @@ def host_fed_leg(spec, mv, off):
     return out
 
 
-def host_fed_batch64(exe, n=12, reps=250):
+def host_fed_batch64(exe, n=12, reps=250, extra_env=None, configs=((64, 1), (16, 4))):
     """BASELINE config 4 through the product-shaped path on ONE device: 64 distinct-seed 1080p dense8x8 streams
     (12 distinct frames each, presented 250x = 3000 frames per stream) through process_batch of the C++ host
     layer at 64 streams x 1 worker and 16 streams x 4 workers; default staging (compact, zero-copy)."""
@@ -294,7 +294,8 @@ def host_fed_batch64(exe, n=12, reps=250):
         for k in ("MTGPU_BATCH_MB", "MTGPU_STAGING"):
             env.pop(k, None)
         env["HIP_VISIBLE_DEVICES"] = (os.environ.get("HIP_VISIBLE_DEVICES") or "0").split(",")[0]
-        for streams, threads in ((64, 1), (16, 4)):
+        env.update(extra_env or {})
+        for streams, threads in configs:
             r = subprocess.run([exe] + paths + ["--streams", str(streams), "--threads", str(threads), "--repeat",
                                                 str(reps), "--summary", "--outdir", tmp], capture_output=True,
                                text=True, env=env, timeout=300)
@@ -326,6 +327,22 @@ def host_fed_batch64(exe, n=12, reps=250):
                                        "pinned_MiB": s["held"]["pinned_bytes"] / 2**20,
                                        "device_MiB": s["held"]["device_bytes"] / 2**20}}
     return res
+
+
+def replayed_traffic(workload, params_name, frames):
+    """(HBM bytes per launch, where the number comes from) for a bench leg, from the committed summary of the
+    builder's own rocprofv3 --pmc passes (scripts/profile_r03.sh) — replayed, never measured by this run."""
+    tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        rec = json.load(open(tp)).get(f"{workload}:{params_name}:{frames}")
+    except Exception:
+        rec = None
+    if not rec:
+        return None, None
+    return rec["hbm_bytes_per_launch"], (
+        f"replayed, not measured in this run: profiles/pmc_traffic.json [{workload}:{params_name}:{frames}], "
+        f"builder-run rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes (gfx950 x2 FETCH correction), "
+        f"{rec.get('collected') or 'round 2'}")
 
 
 def roofline_of(alg_bytes, kern_ms):
@@ -360,6 +377,9 @@ def other_workloads(dev, distinct):
                                 + (" with VECTORS_NEEDED 1 (one record per cell)" if p.vectors_needed == 1 and pn == "code_defaults" else ""),
                     "frames_per_s": frames / (kern_ms * 1e-3), "kernel_ms": kern_ms, "steps": steps,
                     "achieved_GBps": r["achieved"], "frac": r["frac"], "plan": w["scanner"].plan,
+                    "algorithmic_bytes_per_launch": w["alg_bytes"],
+                    "traffic": replayed_traffic(wl, pn, frames)[0],
+                    "traffic_source": replayed_traffic(wl, pn, frames)[1],
                     "motion_frames_in_batch": int(flags.sum())})
         w["scanner"].close()
         del w
@@ -561,18 +581,7 @@ def _run_rank(a):
         value = total_frames / dt
         # HBM bytes per launch: NOT measured by this run (PMC counters need rocprofv3 around the process) —
         # replayed from the committed summary of the builder's own --pmc passes over this same command
-        traffic, traffic_source = None, None
-        tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tp):
-            try:
-                rec = json.load(open(tp)).get(f"{a.workload}:{a.frames}")
-                if rec and a.params == rec.get("params", "code_defaults"):
-                    traffic = rec["hbm_bytes_per_launch"]
-                    traffic_source = ("replayed, not measured in this run: profiles/pmc_traffic.json "
-                                      f"[{a.workload}:{a.frames}], builder-run rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                                      f"passes (gfx950 x2 FETCH correction), {rec.get('collected', 'round 2')}")
-            except Exception:
-                traffic, traffic_source = None, None
+        traffic, traffic_source = replayed_traffic(a.workload, a.params, a.frames)
         cpu = None
         others = None
         host = None
@@ -657,8 +666,10 @@ def cpu_baseline(params, mv, off, gpu_flags, budget_s, workload):
     n0 = len(off) - 1
     flags = ob.scan_frames(params, mv, off, None, nthreads=share)       # warm-up + parity check
     assert np.array_equal(flags, gpu_flags), "GPU flags differ from the oracle on the bench tile"
-    # >= 64 frames per thread of the 16-thread leg, >= 8 per thread of the all-core leg (10 MB: beyond its L2)
-    want = max(64 * share, 8 * cores_usable)
+    # the sample: the distinct frames tiled to >= 8 frames (10 MB, beyond its L2) per thread of the widest leg.
+    # Every thread scans a NUMA-local copy of its share (a worker's own decoder output in the reference),
+    # `reps` times between two barriers: oracle/mt_oracle.c mto_bench_scan times exactly the scanning.
+    want = max(n0, 8 * cores_usable)
     tile = max(1, (want + n0 - 1) // n0)
     counts = np.tile(np.diff(off.astype(np.int64)), tile)
     off = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
@@ -666,14 +677,11 @@ def cpu_baseline(params, mv, off, gpu_flags, budget_s, workload):
     n = len(off) - 1
 
     def leg(threads, seconds):
-        ob.scan_frames(params, mv, off, None, nthreads=threads)        # touch every page from these threads once
-        reps, t0 = 0, time.perf_counter()
-        while True:
-            ob.scan_frames(params, mv, off, None, nthreads=threads)
-            reps += 1
-            dt = time.perf_counter() - t0
-            if dt > seconds or reps >= 10000:
-                return n * reps / dt, reps, dt
+        _, t1 = ob.bench_scan(params, mv, off, None, nthreads=threads, reps=1)       # calibration pass
+        reps = int(max(1, min(100000, seconds / max(t1, 1e-6))))
+        fl, dt = ob.bench_scan(params, mv, off, None, nthreads=threads, reps=reps)
+        assert np.array_equal(fl, np.tile(gpu_flags, tile)[:n]), "oracle flags changed between passes"
+        return n * reps / dt, reps, dt
 
     legs = [(1, 0.15 * budget_s), (share, 0.45 * budget_s)]
     if cores_usable > share:
@@ -682,7 +690,8 @@ def cpu_baseline(params, mv, off, gpu_flags, budget_s, workload):
     v16, reps16, dt16 = res[share]
     out = {"value": v16, "unit": "frames/s", "cores": share, "kind": "port",
            "sample": f"{n} {workload} frames ({n0} distinct, {mv.nbytes / 1e6:.0f} MB) x {reps16} passes "
-                     f"({dt16:.1f} s wall), oracle/mt_oracle.c scan, {share} pthreads",
+                     f"({dt16:.1f} s between barriers), oracle/mt_oracle.c mto_bench_scan, {share} pthreads, "
+                     f"each on a thread-local copy of its share",
            "value_1core": res[1][0], "sample_1core": f"{res[1][1]} passes, {res[1][2]:.1f} s",
            "host_cpu": model, "host_cores_total": cores_total, "host_cores_usable": cores_usable,
            "GBps": {"1": res[1][0] * mv.nbytes / n / 1e9, str(share): v16 * mv.nbytes / n / 1e9}}

@@ -247,6 +247,7 @@ int make_plan(mtgpu_ctx *c, int lds_max, int cu_count) {
   }
   k.slices = 1;
   k.group = 1;
+  k.prefetch = env_int("MTGPU_PREFETCH", 1) != 0 ? 1 : 0;      // experiments: 0 switches the next-frame prefetch off
   c->group_request = env_int("MTGPU_GROUP", 0);
   c->min_lds_kb = env_int("MTGPU_MIN_LDS_KB", 0);
   c->item_chunk = env_int("MTGPU_ITEM_CHUNK", 0);
@@ -293,6 +294,15 @@ int choose_group(const mtgpu_ctx *c, uint64_t n_records, uint32_t n_frames, int 
     const uint64_t cus = (uint64_t)(c->plan.cu_count > 0 ? c->plan.cu_count : 256);
     g = 1;
     while (g < 8 && avg * (uint64_t)(2 * g) <= (1ull << 18) && (uint64_t)n_frames >= cus * 8ull * (uint64_t)(2 * g)) g *= 2;
+    // Compact records on a tile that leaves ONE workgroup per CU (4K: 124 KB of 32-bit counters): nothing overlaps
+    // that workgroup's zeroing and cluster test (5 of 38 us per ~1 MB frame), so it scans 2-4 frames in a row
+    // and issues the next frame's first streaming step before its cluster test (scan_kernels.hip, NextStep).
+    // Round 3, 4K dense8x8 compact: 1024 frames 6.13 -> 6.39 TB/s, 4096 frames 6.54 -> 6.73; 4 MB frames
+    // (960x540) and four-per-CU tiles (1080p) gain nothing or lose, 40-byte records lose 2 % (no prefetch there).
+    if (g == 1 && rec_bytes == MT_COMPACT_BYTES && c->k.prefetch && c->plan.lds_bytes > 80 * 1024 && avg <= (2ull << 20)) {
+      if ((uint64_t)n_frames >= cus * 4ull) g = 4;
+      else if ((uint64_t)n_frames >= cus * 2ull) g = 2;
+    }
   }
   if (g > 64) g = 64;
   return g < 1 ? 1 : g;

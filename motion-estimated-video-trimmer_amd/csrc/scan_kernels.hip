@@ -250,7 +250,9 @@ __device__ __forceinline__ void vote(const MvFields m, const ScanK &k, int t0, i
                                      unsigned int *cnt, const SpillQ &sq) {
   const unsigned int dx = (unsigned int)(m.dst_x - m.src_x);   // |dx| <= 65535
   const unsigned int dy = (unsigned int)(m.dst_y - m.src_y);
-  // dx*dx < 2^32 exactly; the sum needs 34 bits.
+  // dx*dx < 2^32 exactly; the sum needs 34 bits.  (The compiler proves the operands fit 17 bits and already
+  // emits the full-rate v_mul_i32_i24 for the squares; __mul24() must NOT be used here: its library definition
+  // multiplies signed ints, so the optimiser may assume dx*dx < 2^31 and drops the 33rd bit of the sum.)
   const unsigned long long mag =
       (unsigned long long)(dx * dx) + (unsigned long long)(dy * dy);
   const int gx = m.dst_x >> k.shift;
@@ -277,13 +279,25 @@ __device__ __forceinline__ void vote(const MvFields m, const ScanK &k, int t0, i
   }
 }
 
-// One work item (a frame, or a frame slice) by one workgroup.
+// Compact records, several frames per workgroup (k.group > 1): the first streaming step of the NEXT frame is
+// issued while this frame's cluster test and the next frame's zeroing run.  Those phases touch only LDS (their
+// barriers wait on lgkmcnt, not on vector-memory loads), so the 4 x 16 bytes per lane stay in flight across
+// them and the CU's memory queue never runs dry between two frames of a workgroup.  `have` is workgroup-uniform.
+template <int UNROLL>
+struct NextStep {
+  u32x4 d[UNROLL];
+  bool have;
+};
+
+// One work item (a frame, or a frame slice) by one workgroup.  `has_next`: the same workgroup scans item + 1
+// (the following frame) right after this one.
 template <int BLOCK, int UNROLL, int FB, int MODE, int VAR, int REC, bool SPILL>
 __device__ __forceinline__ void scan_item(
     const unsigned char *__restrict__ mv, unsigned long long n_records,
     const unsigned long long *__restrict__ frame_off, const unsigned char *__restrict__ has_sd,
     const unsigned int item, const ScanK &k, unsigned char *__restrict__ flags,
-    unsigned int *spill_q, unsigned int *slice_ws, unsigned int *tickets, unsigned int *lds) {
+    unsigned int *spill_q, unsigned int *slice_ws, unsigned int *tickets, unsigned int *lds,
+    NextStep<UNROLL> &ns, const bool has_next) {
   typedef typename RawOf<REC>::type Raw;
   const int tid = threadIdx.x;
   // item -> frame, or (frame, slice): bands and slices are never both > 1
@@ -297,7 +311,7 @@ __device__ __forceinline__ void scan_item(
   const bool sd = has_sd ? (has_sd[f] != 0) : (r1 > r0);
   if (!sd) {                                   // :219-221 — no side data: false
     if (slice == 0 && tid == 0) flags[f] = 0;
-    return;
+    return;                                    // (ns.have is false here: a step is only pre-issued for frames with side data)
   }
   const unsigned long long q0 = r0;            // the frame's spill queue: one slot per record
   if (!SPILL && k.slices > 1) {                // this workgroup's share of the frame's records
@@ -360,6 +374,15 @@ __device__ __forceinline__ void scan_item(
               vote<FB, MODE, SPILL>(decode(load_compact<VAR>(base + (n - 1ull) * 8ull)), k, t0, t1, cnt, sq);
           }
           unsigned long long p = tid;
+          if (ns.have) {                       // this frame's first step was issued during the previous frame's cluster test
+            ns.have = false;
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+              vote<FB, MODE, SPILL>(decode((u32x2){ns.d[u].x, ns.d[u].y}), k, t0, t1, cnt, sq);
+              vote<FB, MODE, SPILL>(decode((u32x2){ns.d[u].z, ns.d[u].w}), k, t0, t1, cnt, sq);
+            }
+            p += STEP;
+          }
           for (; p + LAST < np; p += STEP) {
             u32x4 d[UNROLL];
 #pragma unroll
@@ -414,6 +437,26 @@ __device__ __forceinline__ void scan_item(
           }
         }
         for (; i < n; i += BLOCK) vote<FB, MODE, SPILL>(decode(load_rec<VAR, REC>(base + i * REC)), k, t0, t1, cnt, sq);
+      }
+      if constexpr (REC == 8 && !SPILL) {
+        if (has_next && k.slices == 1 && k.vec_need != 0u && trows > 0) {   // exactly when the next frame's phase 1 runs
+          // next frame: records [frame_off[f+1], frame_off[f+2]) — same clamps, same pair alignment as above
+          unsigned long long a = frame_off[f + 1], b = frame_off[f + 2];
+          b = b < n_records ? b : n_records;
+          a = a < b ? a : b;
+          const bool sdn = has_sd ? (has_sd[f + 1] != 0) : (b > a);
+          const unsigned char *nb = mv + a * 8ull;
+          const unsigned long long nn = b - a;
+          const unsigned long long nhead = (nn > 0 && ((unsigned long long)(uintptr_t)nb & 8ull) != 0ull) ? 1ull : 0ull;
+          const unsigned long long nnp = (nn - nhead) >> 1;
+          if (sdn && nnp >= (unsigned long long)UNROLL * BLOCK) {     // the whole first step lies inside the frame: uniform
+            const unsigned char *npb = nb + nhead * 8ull;
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u)
+              ns.d[u] = load_pair<VAR>(npb + ((unsigned long long)tid + (unsigned long long)u * BLOCK) * 16ull);
+            ns.have = true;
+          }
+        }
       }
       // queue stores of every wave have left the CU before any wave of this workgroup replays them
       if constexpr (SPILL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -601,13 +644,16 @@ __global__ __launch_bounds__(BLOCK) void scan_frames_kernel(
     unsigned int *spill_q, unsigned int *slice_ws, unsigned int *tickets) {
   extern __shared__ __attribute__((aligned(16))) unsigned int lds[];
   const unsigned int first = item0 + blockIdx.x * (unsigned int)k.group;
+  NextStep<UNROLL> ns;
+  ns.have = false;
   for (int g = 0; g < k.group; ++g) {
     const unsigned int item = first + (unsigned int)g;
     if (item >= n_items) break;
     // (no barrier between items: every LDS read of an item precedes its last barrier, and the
     //  next item's writes start with its own zeroing)
+    const bool has_next = (g + 1 < k.group) && (item + 1u < n_items) && k.prefetch;
     scan_item<BLOCK, UNROLL, FB, MODE, VAR, REC, SPILL>(mv, n_records, frame_off, has_sd, item, k, flags, spill_q,
-                                                         slice_ws, tickets, lds);
+                                                         slice_ws, tickets, lds, ns, has_next);
   }
 }
 

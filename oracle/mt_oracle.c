@@ -1,3 +1,4 @@
+#define _GNU_SOURCE
 /*
  * mt_oracle.c — CPU ORACLE for the MV-scan hot path.  TEST INFRASTRUCTURE ONLY
  * (see mt_oracle.h: who may load it, and why parity is "unpinned").
@@ -19,6 +20,7 @@
 
 #include <math.h>
 #include <pthread.h>
+#include <time.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -203,6 +205,95 @@ int mto_scan_frames_mt(const mt_scan_params *p, const mt_mv *mv, const uint64_t 
   }
   free(th);
   free(jobs);
+  return rc;
+}
+
+/* Timed CPU baseline (bench.py's cpu_baseline leg only).  The reference's model is one scanner per worker
+ * thread, each analysing frames its own decoder has just written into its own memory (src/pipeline.cpp:186-197,
+ * timer bracket src/motion_scanner.cpp:375-380).  So each of `nthreads` pthreads first COPIES its share of the
+ * frames into a buffer it allocates itself (first touch: its own NUMA node), all threads meet at a barrier, every
+ * thread scans its share `reps` times, and the wall time between the two barriers comes back in *seconds (thread
+ * creation, the copies and the join are outside it).  flags = the results of the last pass. */
+typedef struct {
+  mt_job j;
+  int reps;
+  pthread_barrier_t *bar;
+  double *t0, *t1;
+} mt_bench_job;
+
+static double now_sec(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+static void *mt_bench_worker(void *arg) {
+  mt_bench_job *b = (mt_bench_job *)arg;
+  mt_job *j = &b->j;
+  const uint32_t nf = j->f1 - j->f0;
+  const uint64_t r0 = j->frame_off[j->f0], r1 = j->frame_off[j->f1];
+  uint8_t *grid = (uint8_t *)malloc((size_t)j->p->grid_w * j->p->grid_h);
+  mt_mv *lmv = (mt_mv *)malloc((size_t)(r1 - r0) * sizeof(mt_mv) + 64);
+  uint64_t *loff = (uint64_t *)malloc(sizeof(uint64_t) * ((size_t)nf + 1));
+  uint8_t *lsd = (j->has_sd && nf) ? (uint8_t *)malloc(nf) : NULL;
+  uint8_t *lfl = (uint8_t *)malloc((size_t)nf + 1);
+  const int ok = grid && lmv && loff && lfl && (!j->has_sd || !nf || lsd);
+  if (ok) {
+    memcpy(lmv, j->mv + r0, (size_t)(r1 - r0) * sizeof(mt_mv));
+    for (uint32_t f = 0; f <= nf; ++f) loff[f] = j->frame_off[j->f0 + f] - r0;
+    if (lsd) memcpy(lsd, j->has_sd + j->f0, nf);
+  }
+  j->rc = ok ? MT_OK : MT_ERR_NOMEM;
+  if (pthread_barrier_wait(b->bar) == PTHREAD_BARRIER_SERIAL_THREAD) *b->t0 = now_sec();
+  pthread_barrier_wait(b->bar);                      /* nobody starts before t0 is taken */
+  if (ok)
+    for (int r = 0; r < b->reps && j->rc == MT_OK; ++r)
+      j->rc = scan_range_frames(j->p, lmv, loff, lsd, 0, nf, lfl, grid);
+  if (pthread_barrier_wait(b->bar) == PTHREAD_BARRIER_SERIAL_THREAD) *b->t1 = now_sec();
+  if (ok && j->rc == MT_OK) memcpy(j->flags + j->f0, lfl, nf);
+  free(grid); free(lmv); free(loff); free(lsd); free(lfl);
+  return NULL;
+}
+
+int mto_bench_scan(const mt_scan_params *p, const mt_mv *mv, const uint64_t *frame_off, const uint8_t *has_sd,
+                   uint32_t n_frames, uint8_t *flags, int nthreads, int reps, double *seconds) {
+  if (!params_ok(p) || !frame_off || !flags || !seconds || n_frames == 0 || reps < 1) return MT_ERR_INVALID;
+  if (nthreads < 1) nthreads = 1;
+  if ((uint32_t)nthreads > n_frames) nthreads = (int)n_frames;
+  pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * nthreads);
+  mt_bench_job *jobs = (mt_bench_job *)malloc(sizeof(mt_bench_job) * nthreads);
+  pthread_barrier_t bar;
+  if (!th || !jobs || pthread_barrier_init(&bar, NULL, (unsigned)nthreads) != 0) { free(th); free(jobs); return MT_ERR_NOMEM; }
+  double t0 = 0.0, t1 = 0.0;
+  const uint64_t total = frame_off[n_frames] - frame_off[0];
+  uint32_t f = 0;
+  for (int t = 0; t < nthreads; ++t) {               /* same record-balanced static split as mto_scan_frames_mt */
+    uint64_t target = frame_off[0] + (total * (uint64_t)(t + 1)) / (uint64_t)nthreads;
+    uint32_t e = f;
+    if (t == nthreads - 1) e = n_frames;
+    else while (e < n_frames && frame_off[e + 1] <= target) ++e;
+    if (e == f && f < n_frames && (n_frames - f) > (uint32_t)(nthreads - 1 - t)) e = f + 1;
+    jobs[t].j = (mt_job){p, mv, frame_off, has_sd, flags, f, e, MT_OK};
+    jobs[t].reps = reps; jobs[t].bar = &bar; jobs[t].t0 = &t0; jobs[t].t1 = &t1;
+    f = e;
+  }
+  int started = 0, rc = MT_OK;
+  for (; started < nthreads; ++started)
+    if (pthread_create(&th[started], NULL, mt_bench_worker, &jobs[started]) != 0) break;
+  if (started < nthreads) {                          /* cannot run short of a full barrier party: give up cleanly */
+    for (int t = 0; t < started; ++t) pthread_cancel(th[t]);
+    for (int t = 0; t < started; ++t) pthread_join(th[t], NULL);
+    rc = MT_ERR_NOMEM;
+  } else {
+    for (int t = 0; t < nthreads; ++t) {
+      pthread_join(th[t], NULL);
+      if (jobs[t].j.rc != MT_OK) rc = jobs[t].j.rc;
+    }
+  }
+  pthread_barrier_destroy(&bar);
+  free(th);
+  free(jobs);
+  *seconds = t1 - t0;
   return rc;
 }
 

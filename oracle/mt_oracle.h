@@ -61,6 +61,12 @@ int mto_scan_frames(const mt_scan_params *p, const mt_mv *mv, const uint64_t *fr
 int mto_scan_frames_mt(const mt_scan_params *p, const mt_mv *mv, const uint64_t *frame_off,
                        const uint8_t *has_sd, uint32_t n_frames, uint8_t *flags, int nthreads);
 
+/* bench.py's cpu_baseline leg only: every thread copies its share of the frames into memory it allocates itself
+ * (NUMA-local, like a worker's own decoder output), then all threads scan their shares `reps` times between two
+ * barriers; *seconds = that wall time.  flags = results of the last pass. */
+int mto_bench_scan(const mt_scan_params *p, const mt_mv *mv, const uint64_t *frame_off, const uint8_t *has_sd,
+                   uint32_t n_frames, uint8_t *flags, int nthreads, int reps, double *seconds);
+
 /* src/motion_scanner.cpp:307-313. */
 int mto_frame_skip(double video_fps, double target_fps);
 

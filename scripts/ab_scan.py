@@ -36,6 +36,10 @@ VARIANTS_TILE = [("single", dict()), ("bands80", dict(MTGPU_MAX_TILE_KB="80")),
                  ("bands53", dict(MTGPU_MAX_TILE_KB="53", MTGPU_BAND_LDS_KB="53"))]
 VARIANTS_GROUP = [("auto", dict()), ("g1", dict(MTGPU_GROUP="1")), ("g2", dict(MTGPU_GROUP="2")), ("g4", dict(MTGPU_GROUP="4")),
                   ("g8", dict(MTGPU_GROUP="8"))]
+# compact records: frames per workgroup x next-frame prefetch (use with AB_COMPACT=1)
+VARIANTS_PREFETCH = [("g1", dict(MTGPU_GROUP="1")), ("g2/pf", dict(MTGPU_GROUP="2")), ("g2/nopf", dict(MTGPU_GROUP="2", MTGPU_PREFETCH="0")),
+                     ("g4/pf", dict(MTGPU_GROUP="4")), ("g4/nopf", dict(MTGPU_GROUP="4", MTGPU_PREFETCH="0")),
+                     ("g8/pf", dict(MTGPU_GROUP="8")), ("auto", dict())]
 # workgroups per CU, capped through the LDS size of the launch (32-bit counters on a 1080p / 4K grid)
 VARIANTS_OCC = [("auto", dict()), ("lds40", dict(MTGPU_MIN_LDS_KB="40")), ("lds53", dict(MTGPU_MIN_LDS_KB="53")),
                 ("lds80", dict(MTGPU_MIN_LDS_KB="80")), ("lds160", dict(MTGPU_MIN_LDS_KB="160"))]
@@ -81,10 +85,11 @@ def main():
             alg = 8 * int(off_big[-1]) + 9 * frames
         scanners = []
         vset = {"fine": VARIANTS_FINE, "kernel": VARIANTS_KERNEL, "slices": VARIANTS_SLICES,
-                "bands": VARIANTS_BANDS, "tile": VARIANTS_TILE, "group": VARIANTS_GROUP, "occ": VARIANTS_OCC}.get(os.environ.get("AB_SET"), VARIANTS)
+                "bands": VARIANTS_BANDS, "tile": VARIANTS_TILE, "group": VARIANTS_GROUP, "occ": VARIANTS_OCC,
+                "prefetch": VARIANTS_PREFETCH}.get(os.environ.get("AB_SET"), VARIANTS)
         for name, env in vset:
             for k in ("MTGPU_FORCE_FB", "MTGPU_FORCE_BLOCK", "MTGPU_FORCE_CHUNK", "MTGPU_VARIANT", "MTGPU_FORCE_SLICES",
-                      "MTGPU_BAND_LDS_KB", "MTGPU_MAX_TILE_KB", "MTGPU_GROUP", "MTGPU_MIN_LDS_KB"):
+                      "MTGPU_BAND_LDS_KB", "MTGPU_MAX_TILE_KB", "MTGPU_GROUP", "MTGPU_MIN_LDS_KB", "MTGPU_PREFETCH"):
                 os.environ.pop(k, None)
             os.environ.update(env)
             try:

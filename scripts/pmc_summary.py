@@ -2,7 +2,7 @@
 """Summarise rocprofv3 runs of bench.py into the small files kept under profiles/.
 
   pmc_summary.py stats  <kernel_stats.csv> <out.csv>            keep the rows of our kernels (+ top others)
-  pmc_summary.py pmc    <bench.json> <fetch_dir> <write_dir|-> <key> <out.json>
+  pmc_summary.py pmc    <bench.json> <fetch_dir> <write_dir|-> <key> <out.json> [collected-by note]
         HBM bytes per scan_frames_kernel launch from separate --pmc FETCH_SIZE / WRITE_SIZE passes,
         corrected as MI355X_MICROARCH.md "HBM" prescribes for gfx950 (counter unit KB; FETCH_SIZE x2),
         next to the algorithmic bytes per launch that bench.py printed; merged into <out.json> under <key>.
@@ -41,6 +41,7 @@ def main():
         csv.writer(open(dst, "w", newline="")).writerows(keep)
         return
     bench_json, fetch_dir, write_dir, key, out = sys.argv[2:7]
+    collected = sys.argv[7] if len(sys.argv) > 7 else None
     line = [ln for ln in open(bench_json) if ln.startswith("{")][-1]
     b = json.loads(line)
     alg = b["roofline"]["algorithmic_bytes_per_launch"]
@@ -49,7 +50,8 @@ def main():
     if write_dir != "-":
         w_kb, _ = counter_mean(write_dir, "WRITE_SIZE")
     hbm = f_kb * 1024.0 * 2.0 + (w_kb * 1024.0 if w_kb is not None else 0.0)
-    rec = {"workload": b["config"]["workload"], "launches_averaged": nf, "FETCH_SIZE_KB_raw": f_kb,
+    rec = {"workload": b["config"]["workload"], "collected": collected, "kernel_ms_in_stats_run": b["roofline"]["kernel_ms"],
+           "launches_averaged": nf, "FETCH_SIZE_KB_raw": f_kb,
            "WRITE_SIZE_KB_raw": w_kb,
            "correction": "gfx950: FETCH_SIZE x2 (MI355X_MICROARCH.md, HBM section); counter unit KB; FETCH_SIZE and "
                          "WRITE_SIZE in separate --pmc passes",

@@ -34,6 +34,8 @@ def lib():
                                       C.c_uint32, C.c_void_p]
         L.mto_scan_frames_mt.restype = C.c_int
         L.mto_scan_frames_mt.argtypes = L.mto_scan_frames.argtypes + [C.c_int]
+        L.mto_bench_scan.restype = C.c_int
+        L.mto_bench_scan.argtypes = L.mto_scan_frames.argtypes + [C.c_int, C.c_int, C.POINTER(C.c_double)]
         L.mto_frame_skip.restype = C.c_int
         L.mto_frame_skip.argtypes = [C.c_double, C.c_double]
         L.mto_filter_frames.restype = C.c_int64
@@ -94,6 +96,22 @@ def scan_frames(params, mv, frame_off, has_sd=None, nthreads=1):
     if rc:
         raise ValueError(f"mto_scan_frames -> {rc}")
     return flags
+
+
+def bench_scan(params, mv, frame_off, has_sd=None, nthreads=1, reps=1):
+    """(flags, seconds): `reps` passes of every thread over its NUMA-local copy of its share, timed between
+    barriers inside the C code (bench.py's cpu_baseline leg)."""
+    c = params.to_c()
+    mv = np.ascontiguousarray(mv, dtype=m.MV_DTYPE)
+    off = np.ascontiguousarray(frame_off, dtype=np.uint64)
+    sd = None if has_sd is None else np.ascontiguousarray(has_sd, dtype=np.uint8)
+    n = len(off) - 1
+    flags = np.zeros(n, dtype=np.uint8)
+    sec = C.c_double(0.0)
+    rc = lib().mto_bench_scan(C.byref(c), _p(mv), _p(off), _p(sd), n, _p(flags), int(nthreads), int(reps), C.byref(sec))
+    if rc:
+        raise ValueError(f"mto_bench_scan -> {rc}")
+    return flags, float(sec.value)
 
 
 def filter_frames(frame_pts, time_base, start, end, skip):

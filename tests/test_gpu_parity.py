@@ -293,6 +293,44 @@ def test_scan_edge_configs(gpu_scanner_factory, width, height, kw, force_fb):
     del want
 
 
+BIG_D = [((65535, 65535), (65519, 65535)),      # 8 589 672 450 and 8 587 575 586: the largest sums int16 fields allow
+         ((65535, 0), (65519, 0)),              # 4 294 836 225 (just below 2^32) and 4 292 739 361
+         ((65535, 362), (65519, 2000)),         # 4 294 967 269 < 2^32 <= 4 296 739 361
+         ((65535, 363), (65519, 2000)),         # 4 294 967 994 > 2^32: a sum truncated to 32 bits would read 698
+         ((46341, 46341), (46340, 46341))]      # 4 294 976 562 and 4 294 883 881 on either side of 2^32
+
+
+@pytest.mark.parametrize("thr", [4294836225.0, 4294836225.5, 4294967296.0, 4294967994.0, 4294967994.5, 8587575586.0,
+                                 8587575586.5, 8589672450.0, 8589672450.5, 16.0])
+def test_scan_magnitude_beyond_32_bits(gpu_scanner_factory, thr):
+    """|d|^2 needs 34 bits when both differences span the whole int16 range.  Outside the reference's defined
+    domain (signed overflow there); oracle and HIP path define it as the exact 64-bit magnitude.
+    Two adjacent cells (the last two columns of a 2048 x 2048-cell grid, so dst = 32767 is inside it) each get one
+    record; the frame fires iff BOTH magnitudes are >= the threshold (strict `<` of motion_scanner.cpp:251) —
+    expected values from exact Python integers, thresholds on both sides of 2^32 and of the largest sums; through
+    40-byte records and through the compact-record pipe (banded plan: 4 M cells)."""
+    import math
+    p = ob.params_from_config(32768, 32768, mv_threshold_sq=thr, vectors_needed=1, clusters_needed=1, vertical_mask=0.0)
+    assert (p.grid_w, p.grid_h, p.vertical_margin) == (2048, 2048, 0)
+    s = gpu_scanner_factory(p)
+    frames, expect = [], []
+    for (da, db) in BIG_D:
+        mv = np.zeros(2, dtype=m.MV_DTYPE)
+        mv["dst_x"], mv["dst_y"] = [32767, 32751], 32767                 # cells (2047, 2047) and (2046, 2047)
+        mv["src_x"] = [32767 - da[0], 32751 - db[0]]
+        mv["src_y"] = [32767 - da[1], 32767 - db[1]]
+        frames.append(mv)
+        expect.append(int(all(dx * dx + dy * dy >= math.ceil(thr) for dx, dy in (da, db))))
+    b = m.FrameBatch.from_frames(frames)
+    want = assert_scan_parity(s, p, b.mv, b.frame_off, b.has_sd)
+    assert want.tolist() == expect
+    pipe = m.ScanPipe(s, 16, 8, 2)
+    for i, f in enumerate(frames):
+        pipe.feed(f, float(i), tag=i)
+    assert [fl for _, fl, _ in pipe.drain()] == expect
+    pipe.close()
+
+
 def test_scan_counter_saturation(gpu_scanner_factory):
     """> 255 votes in one cell (the reference's u8 saturates at 255, :265-266) and
     vectors_needed = 255: active iff >= 255 votes."""
@@ -913,6 +951,75 @@ def test_scan_frames_per_workgroup_grouping(gpu_scanner_factory, monkeypatch):
                                                 torch.from_numpy(off.astype(np.int64)).cuda(),
                                                 torch.from_numpy(sd).cuda()).cpu().numpy()
             assert np.array_equal(got, want), (w, g, "compact")
+
+
+@pytest.mark.parametrize("grid", ["1080p", "4k"])
+def test_compact_next_frame_prefetch(gpu_scanner_factory, monkeypatch, grid):
+    """Compact records, several frames per workgroup: the first streaming step of the next frame is issued before
+    this frame's cluster test (scan_kernels.hip, NextStep).  Frame sizes on both sides of one full step
+    (4 x BLOCK pairs), odd record counts (the next frame then starts 8 bytes off a 16-byte boundary), empty
+    frames, frames without side data and I-frame gaps inside a group, a group's last frame, batches that end
+    inside a group; with the prefetch on and off, the flags must be the oracle's."""
+    import torch
+    w, h = (1920, 1080) if grid == "1080p" else (3840, 2160)
+    block = 512 if grid == "1080p" else 1024
+    step = 2 * 4 * block                                 # records of one full streaming step (4 pairs per lane)
+    rng = np.random.RandomState(77 + block)
+    sizes = [0, 1, step - 1, step, step + 1, step + 2, 2 * step + 3, 3 * step + 1, 17, 5 * step, step, step + 5,
+             step - 2, 0, 2 * step, 2 * step + 1, step + 7, 40001, step, 3, step + 9, 6 * step + 1, step, step, step + 1]
+    # Every record is still (|d|^2 = 1) except a handful of voters: with VECTORS_NEEDED = 2 an "A" frame gives
+    # two adjacent cells exactly 2 votes each (flag 1; one lost record -> 0), a "B" frame gives the second cell
+    # a single vote (flag 0; one record counted twice -> 1).  Voters sit at the very first / last record (the
+    # odd head / tail a lane handles alone), inside the first streaming step (the pre-issued one) and beyond it.
+    frames, kinds = [], []
+    for i, n in enumerate(sizes):
+        mv = np.zeros(n, dtype=m.MV_DTYPE)
+        mv["dst_x"] = rng.randint(0, w, size=n)
+        mv["dst_y"] = rng.randint(0, h, size=n)
+        mv["src_x"], mv["src_y"] = mv["dst_x"] - 1, mv["dst_y"]
+        kind = "AB"[i % 2] if n >= 4 else "-"
+        if kind != "-":
+            cx, cy = int(rng.randint(2, w // 16 - 3)), int(rng.randint(h // 160 + 2, h // 16 - h // 160 - 3))
+            pos = {0, n - 1, int(rng.randint(0, min(n, step))), int(rng.randint(n // 2, n))}
+            while len(pos) < 4:
+                pos.add(int(rng.randint(0, n)))
+            pos = sorted(pos)
+            cells = [(cx, cy), (cx + 1, cy), (cx, cy), (cx + 1, cy)]
+            rng.shuffle(cells)
+            if kind == "B":
+                cells[cells.index((cx + 1, cy))] = (cx + 5, cy + 3)       # the second cell keeps ONE vote
+            for q, (gx, gy) in zip(pos, cells):
+                mv["dst_x"][q], mv["dst_y"][q] = gx * 16 + 8, gy * 16 + 8
+                mv["src_x"][q], mv["src_y"][q] = gx * 16 + 8 - 6, gy * 16 + 8       # |d|^2 = 36 >= 16
+        frames.append(mv if i % 9 != 4 else None)         # every 9th frame: no side data at all
+        kinds.append(kind if i % 9 != 4 else "-")
+    b = m.FrameBatch.from_frames(frames)
+    assert len(set(int(x) & 1 for x in b.frame_off)) == 2                     # both alignments of a frame start occur
+    rec = m.pack_records(b.mv)
+    d_rec = torch.from_numpy(rec.view(np.uint8).reshape(-1).copy()).cuda()
+    d_off = torch.from_numpy(b.frame_off.astype(np.int64)).cuda()
+    d_sd = torch.from_numpy(b.has_sd).cuda()
+    for kw in (dict(vectors_needed=2, clusters_needed=1), dict(vectors_needed=1, clusters_needed=2), dict(vectors_needed=0)):
+        p = ob.params_from_config(w, h, **kw)
+        want = ob.scan_frames(p, b.mv, b.frame_off, b.has_sd)
+        want_nosd = ob.scan_frames(p, b.mv, b.frame_off, None)
+        if kw["vectors_needed"] == 2:
+            assert want.tolist() == [1 if k == "A" else 0 for k in kinds]
+        for g, pf in ((2, 1), (3, 1), (4, 1), (8, 1), (25, 1), (64, 1), (4, 0), (1, 1)):
+            monkeypatch.setenv("MTGPU_GROUP", str(g))
+            monkeypatch.setenv("MTGPU_PREFETCH", str(pf))
+            s = gpu_scanner_factory(m.ScanParams.from_config(w, h, **kw))
+            monkeypatch.delenv("MTGPU_GROUP")
+            monkeypatch.delenv("MTGPU_PREFETCH")
+            assert s.plan["block_threads"] == block and s.plan["counter_bits"] == 32
+            got = s.check_frames_device_compact(d_rec, d_off, d_sd).cpu().numpy()
+            assert np.array_equal(got, want), (grid, kw, g, pf)
+            got = s.check_frames_device_compact(d_rec, d_off, None).cpu().numpy()
+            assert np.array_equal(got, want_nosd), (grid, kw, g, pf, "has_sd NULL")
+            # a window that starts at an odd record and ends inside a group
+            lo, hi = 2, len(sizes) - 3
+            got = s.check_frames_device_compact(d_rec, d_off[lo:hi + 1].contiguous(), d_sd[lo:hi].contiguous()).cpu().numpy()
+            assert np.array_equal(got, want[lo:hi]), (grid, kw, g, pf, "window")
 
 
 def test_plain_c_example(tmp_path):

@@ -276,3 +276,18 @@ def test_oracle_vs_numpy_model_hypothesis():
         assert ob.check_frame(p, mv, has_sd) == flag
 
     check()
+
+
+def test_bench_scan_is_the_same_scan():
+    """mto_bench_scan (bench.py's timed CPU baseline: thread-local copies, passes between barriers) returns the
+    flags of mto_scan_frames for every thread count, with and without has_sd, on ragged frames."""
+    rng = np.random.RandomState(12)
+    mv, off, sd = synth.random_frames(rng, 37, 500, 640, 480)
+    p = ob.params_from_config(640, 480, vectors_needed=1)
+    want = ob.scan_frames(p, mv, off, sd)
+    want_nosd = ob.scan_frames(p, mv, off, None)
+    for threads in (1, 2, 5, 37, 64):
+        fl, sec = ob.bench_scan(p, mv, off, sd, nthreads=threads, reps=3)
+        assert np.array_equal(fl, want) and sec > 0.0
+        fl, _ = ob.bench_scan(p, mv, off, None, nthreads=threads, reps=1)
+        assert np.array_equal(fl, want_nosd)
