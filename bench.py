@@ -315,7 +315,9 @@ def host_fed_batch64(exe, n=12, reps=250, extra_env=None, configs=((64, 1), (16,
                 # last result of that video) x streams = the steady-state rate, without context / pipe set-up
                 "frames_per_s_steady": (float(np.mean([j["frames_scanned"] / max(j["scan_work_us"] * 1e-6, 1e-9)
                                                        for j in jobs])) * streams) if jobs else None,
-                "wall_ms": s["wall_us"] / 1e3,
+                "wall_ms": s["wall_us"] / 1e3, "wall_ms_until_last_video": s.get("scan_wall_us", 0) / 1e3,
+                "setup_ms": {"mtgpu_create_total": s["held"].get("ctx_create_us", 0) / 1e3,
+                             "mtgpu_pipe_create_per_worker": s["held"].get("pipe_create_us", 0) / 1e3 / max(workers, 1)},
                 "worker_time_share": {"init": s["init_us"] / (workers * wall * 1e6),
                                       "reading_frames": s["decode_us"] / busy,
                                       "copy_out_to_pinned": s["copy_us"] / busy,

@@ -85,8 +85,8 @@ typedef struct mtgpu_ctx_stats {
   uint32_t private_pool;          /* 1: scratch from the private pool; 0: device default pool   */
 } mtgpu_ctx_stats;
 int mtgpu_get_stats(mtgpu_ctx *ctx, mtgpu_ctx_stats *out);
-/* Return the scratch pool's unused blocks to the device.  Call it when nothing of this context
- * is in flight (between videos); scans that follow simply map scratch again. */
+/* Return the scratch pool's UNUSED blocks to the device (scratch of launches still in flight stays);
+ * safe at any time, from any thread; scans that follow simply map scratch again. */
 int mtgpu_trim(mtgpu_ctx *ctx);
 
 /* Launch plan chosen for the context's grid (for reports and tests). */

@@ -233,59 +233,115 @@ class MtmvSource : public FrameSource {
 struct Resources {
   uint64_t contexts = 0, pipes = 0, hip_streams = 0, hip_events = 0, mem_pools = 0;
   uint64_t pinned_bytes = 0, device_bytes = 0, pool_reserved_high = 0, submits = 0;
+  uint64_t ctx_create_us = 0, pipe_create_us = 0;        // set-up time spent in mtgpu_create / mtgpu_pipe_create_layout
   void add(const Resources &o) {
+    ctx_create_us += o.ctx_create_us; pipe_create_us += o.pipe_create_us;
     contexts += o.contexts; pipes += o.pipes; hip_streams += o.hip_streams; hip_events += o.hip_events;
     mem_pools += o.mem_pools; pinned_bytes += o.pinned_bytes; device_bytes += o.device_bytes;
     pool_reserved_high += o.pool_reserved_high; submits += o.submits;
   }
 };
 
-class GpuBackend {
+// One scan context per (device, parameter block) for the whole process, shared by every worker thread that
+// needs it.  A context holds no per-frame state (the vote grid lives in LDS, launch scratch is stream-ordered,
+// include/mtgpu.h: "may be called from many host threads"), so the reference's one-MotionScanner-per-worker
+// model (src/pipeline.cpp:186-197) needs only a PIPE per worker: 64 streams x T workers then cost 1 context,
+// 1 scratch pool and 1 context stream per device instead of 64 x T of each (profiles/r03_host_batch64.json:
+// mtgpu_create took 0.3 s per worker when 64 threads called it at once).  The last user destroys the context.
+class SharedContext {
   mtgpu_ctx *ctx_ = nullptr;
+ public:
+  int device = -1;
+  mt_scan_params params{};
+  uint64_t create_us = 0;
+  explicit SharedContext(mtgpu_ctx *c) : ctx_(c) {}
+  ~SharedContext() { if (ctx_) mtgpu_destroy(ctx_); }
+  SharedContext(const SharedContext &) = delete;
+  SharedContext &operator=(const SharedContext &) = delete;
+  mtgpu_ctx *get() const { return ctx_; }
+
+  static std::shared_ptr<SharedContext> acquire(const mt_scan_params &p, int device, std::string &err) {
+    static std::mutex mu;
+    static std::vector<std::weak_ptr<SharedContext>> live;
+    std::lock_guard<std::mutex> l(mu);          // creation is serialised: the second caller finds the first one's context
+    for (auto it = live.begin(); it != live.end();) {
+      std::shared_ptr<SharedContext> sp = it->lock();
+      if (!sp) { it = live.erase(it); continue; }
+      if (sp->device == device && std::memcmp(&sp->params, &p, sizeof p) == 0) return sp;
+      ++it;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    mtgpu_ctx *c = nullptr;
+    if (mtgpu_create(&p, device, &c) != MT_OK) { err = mtgpu_last_error(); return nullptr; }
+    auto sp = std::make_shared<SharedContext>(c);
+    sp->device = device;
+    sp->params = p;                              // (mtgpu_params_from_config zero-fills the padding: memcmp is exact)
+    sp->create_us = (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+    live.push_back(sp);
+    return sp;
+  }
+};
+
+class GpuBackend {
+  std::shared_ptr<SharedContext> shared_;
   mtgpu_pipe *pipe_ = nullptr;
   int width_ = -1, height_ = -1, device_ = -1;
+  uint64_t pipe_us_ = 0;
  public:
   GpuBackend() = default;
   ~GpuBackend() { reset(); }
   GpuBackend(const GpuBackend &) = delete;
   GpuBackend &operator=(const GpuBackend &) = delete;
   void reset() {
-    if (pipe_) mtgpu_pipe_destroy(pipe_);
-    if (ctx_) mtgpu_destroy(ctx_);
-    pipe_ = nullptr; ctx_ = nullptr; width_ = height_ = device_ = -1;
+    if (pipe_) mtgpu_pipe_destroy(pipe_);        // the pipe first: it launches on the context
+    pipe_ = nullptr;
+    shared_.reset();
+    width_ = height_ = device_ = -1;
   }
-  mtgpu_ctx *ctx() { return ctx_; }
+  mtgpu_ctx *ctx() { return shared_ ? shared_->get() : nullptr; }
   mtgpu_pipe *pipe() { return pipe_; }
+  const void *context_identity() const { return shared_.get(); }
+  // What THIS worker holds: its pipe.  The shared context is reported by context_resources(), once per context.
   Resources resources() {
     Resources r;
-    mtgpu_ctx_stats cs;
+    r.pipe_create_us = pipe_us_;
     mtgpu_pipe_stats ps;
-    if (ctx_ && mtgpu_get_stats(ctx_, &cs) == MT_OK) {
-      r.contexts = 1; r.hip_streams += cs.hip_streams; r.mem_pools = cs.private_pool;
-      r.device_bytes += cs.staging_device_bytes + cs.pool_reserved_high; r.pool_reserved_high = cs.pool_reserved_high;
-    }
     if (pipe_ && mtgpu_pipe_get_stats(pipe_, &ps) == MT_OK) {
       r.pipes = 1; r.hip_streams += ps.n_buffers; r.hip_events += ps.n_buffers;
       r.pinned_bytes += ps.pinned_bytes; r.device_bytes += ps.device_bytes; r.submits = ps.submits;
     }
     return r;
   }
+  Resources context_resources() {
+    Resources r;
+    mtgpu_ctx_stats cs;
+    if (shared_ && mtgpu_get_stats(shared_->get(), &cs) == MT_OK) {
+      r.contexts = 1; r.hip_streams += cs.hip_streams; r.mem_pools = cs.private_pool;
+      r.device_bytes += cs.staging_device_bytes + cs.pool_reserved_high; r.pool_reserved_high = cs.pool_reserved_high;
+      r.ctx_create_us = shared_->create_us;
+    }
+    return r;
+  }
   // between two videos: hand the scratch pool's cached blocks back (the spill queue of a banded plan is
-  // 4 bytes per record of the largest batch ever scanned — per context, times N x S workers)
-  void trim() { if (ctx_) (void)mtgpu_trim(ctx_); }
+  // 4 bytes per record of the largest batch ever scanned); only unused blocks go, other workers' launches
+  // on the shared context are not disturbed
+  void trim() { if (shared_) (void)mtgpu_trim(shared_->get()); }
   // cfg/grid derivation of MotionScanner::initialize (motion_scanner.cpp:184-199) + device setup;
   // a backend already set up for this frame size and device is reused as it is.
   bool ensure(int width, int height, int device, uint64_t batch_records, uint32_t batch_frames, int n_buffers,
               std::string &err) {
-    if (ctx_ && pipe_ && width == width_ && height == height_ && device == device_) return true;
+    if (shared_ && pipe_ && width == width_ && height == height_ && device == device_) return true;
     reset();
     mt_scan_params p;
     int rc = mtgpu_params_from_config(&p, width, height, Config::mv_threshold_sq(), Config::block_size(),
                                       Config::block_shift(), Config::vectors_needed(), Config::clusters_needed(),
                                       Config::vertical_mask());
-    if (rc == MT_OK) rc = mtgpu_create(&p, device, &ctx_);
-    if (rc == MT_OK)
-      rc = mtgpu_pipe_create_layout(ctx_, batch_records, batch_frames, n_buffers, Config::staging_layout(), &pipe_);
+    if (rc != MT_OK) { err = mtgpu_last_error(); return false; }
+    shared_ = SharedContext::acquire(p, device, err);
+    if (!shared_) return false;
+    const auto t1 = std::chrono::steady_clock::now();
+    rc = mtgpu_pipe_create_layout(shared_->get(), batch_records, batch_frames, n_buffers, Config::staging_layout(), &pipe_);
+    pipe_us_ += (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t1).count();
     if (rc != MT_OK) { err = mtgpu_last_error(); reset(); return false; }
     width_ = width; height_ = height; device_ = device;
     return true;
@@ -619,7 +675,8 @@ struct BatchSummary {   // what a whole process_batch run did and what it held (
   int streams = 0, threads_per_stream = 0;
   size_t videos = 0, jobs = 0, failed = 0;
   uint64_t frames_scanned = 0;
-  long wall_us = 0;                                        // first stream thread started -> last one finished
+  long wall_us = 0;                                        // first stream thread started -> last one finished (teardown included)
+  long scan_wall_us = 0;                                   // ... -> last video finished (contexts / pipes still alive)
   long init_us = 0, decode_us = 0, analyze_us = 0, copy_us = 0, submit_us = 0, wait_us = 0;   // summed over all workers
   Resources held;                                          // summed over the S x T backends alive at the end
 };
@@ -634,6 +691,7 @@ int process_batch(const std::vector<std::string> &files, const std::string &outp
   size_t next = 0;
   std::atomic<int> failed{0};
   BatchSummary sum;
+  std::vector<const void *> seen_ctx;
   sum.streams = parallel_streams;
   sum.threads_per_stream = threads_per_stream;
   sum.videos = files.size();
@@ -646,11 +704,32 @@ int process_batch(const std::vector<std::string> &files, const std::string &outp
       for (int i = 0; i < threads_per_stream; ++i) pool.emplace_back(new GpuBackend());
       struct AtExit {                                      // every way out of the loop reports what this stream held
         std::vector<std::unique_ptr<GpuBackend>> &pool; std::mutex &mu; BatchSummary &sum;
-        ~AtExit() { std::lock_guard<std::mutex> l(mu); for (auto &b : pool) sum.held.add(b->resources()); }
-      } at_exit{pool, s_mu, sum};
+        std::vector<const void *> &seen;
+        ~AtExit() {
+          std::lock_guard<std::mutex> l(mu);
+          for (auto &b : pool) {
+            sum.held.add(b->resources());
+            const void *id = b->context_identity();          // a shared context is counted once for the whole batch
+            if (id && std::find(seen.begin(), seen.end(), id) == seen.end()) {
+              seen.push_back(id);
+              sum.held.add(b->context_resources());
+            }
+          }
+        }
+      } at_exit{pool, s_mu, sum, seen_ctx};
       for (;;) {
         size_t idx;
-        { std::lock_guard<std::mutex> l(q_mu); if (next >= files.size()) return; idx = next++; }   // get_next_file
+        {
+          std::lock_guard<std::mutex> l(q_mu);                                                     // get_next_file
+          if (next >= files.size()) {
+            const long now = (long)std::chrono::duration_cast<std::chrono::microseconds>(
+                                 std::chrono::high_resolution_clock::now() - wall0).count();
+            std::lock_guard<std::mutex> l2(s_mu);
+            sum.scan_wall_us = std::max(sum.scan_wall_us, now);
+            return;
+          }
+          idx = next++;
+        }
         const std::string &in = files[idx];
         ScanJob job;
         job.stream_id = s;

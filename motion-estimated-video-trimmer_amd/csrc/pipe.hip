@@ -54,6 +54,9 @@ struct mtgpu_batch {
   uint8_t *d_flags = nullptr;
   size_t hdr_bytes = 0;
   size_t stage_bytes = 0;             // size of h_stage (and of d_stage when it exists)
+  size_t aux_bytes = 0;               // pts + tag + flag arrays (pinned; flags mirrored on the device without zero-copy)
+  bool own_stage = false;             // h_stage / d_stage are this batch's own blocks (grown for an oversize frame),
+                                      // not slices of the pipe's slabs
   uint64_t cap_records = 0, n_records = 0;
   uint32_t cap_frames = 0, n_frames = 0;
   int rec_bytes = MT_COMPACT_BYTES;   // bytes per staged record: 8 (compact) or 40 (AoS)
@@ -66,6 +69,11 @@ struct mtgpu_batch {
 
 struct mtgpu_pipe {
   mtgpu_ctx *ctx = nullptr;
+  // ONE pinned slab (and, without zero-copy, one device slab) holds the staging of every batch: a pipe is set
+  // up with two allocations instead of six per batch — with 64 x T worker threads creating their pipes at
+  // once the driver serialises those calls, and 768 of them took ~0.7 s per worker (profiles/r03_host_batch64.json)
+  unsigned char *h_slab = nullptr, *d_slab = nullptr;
+  size_t slab_bytes = 0, d_slab_bytes = 0;
   int rec_bytes = MT_COMPACT_BYTES;
   bool zero_copy = false;
   long inject_submit_fail = 0;   // MTGPU_INJECT_SUBMIT_FAIL=k (tests): the k-th submit fails after its copies were queued
@@ -87,15 +95,44 @@ using mtgpu::hip_fail;
 void free_batch(mtgpu_batch *b) {
   if (!b) return;
   if (b->stream) (void)hipStreamSynchronize(b->stream);
-  if (b->h_stage) (void)hipHostFree(b->h_stage);
-  if (b->h_pts) (void)hipHostFree(b->h_pts);
-  if (b->h_tag) (void)hipHostFree(b->h_tag);
-  if (b->h_flags) (void)hipHostFree(b->h_flags);
-  if (b->d_stage) (void)hipFree(b->d_stage);
-  if (b->d_flags && !b->zero_copy) (void)hipFree(b->d_flags);
+  if (b->own_stage) {
+    if (b->h_stage) (void)hipHostFree(b->h_stage);
+    if (b->d_stage) (void)hipFree(b->d_stage);
+  }
   if (b->done) (void)hipEventDestroy(b->done);
   if (b->stream) (void)hipStreamDestroy(b->stream);
   delete b;
+}
+
+size_t stage_bytes_for(uint32_t cap_frames, uint64_t records, int rec_bytes, size_t *hdr_out) {
+  const size_t nf = (size_t)cap_frames;
+  const size_t hdr = (sizeof(uint64_t) * (nf + 1) + (nf + 1) + 63u) & ~(size_t)63u;
+  if (hdr_out) *hdr_out = hdr;
+  return (hdr + (size_t)records * (size_t)rec_bytes + 64 + 63u) & ~(size_t)63u;
+}
+
+size_t aux_bytes_for(uint32_t cap_frames) {          // [pts (nf+1) x 8 | tags (nf+1) x 8 | flags nf+1], 64-byte aligned
+  const size_t nf = (size_t)cap_frames + 1;
+  return (nf * (sizeof(double) + sizeof(uint64_t)) + nf + 63u) & ~(size_t)63u;
+}
+
+// Point a batch's staging at `h` (pinned) / `dv` (what the kernel dereferences: the device view of the pinned
+// block with zero-copy, device memory otherwise) / `d_own` (the device block to free later, or nullptr).
+void set_stage(mtgpu_batch *b, unsigned char *h, unsigned char *dv, unsigned char *d_own, size_t hdr, size_t bytes,
+               uint64_t records) {
+  const size_t nf = (size_t)b->cap_frames;
+  b->h_stage = h;
+  b->d_stage = d_own;
+  b->hdr_bytes = hdr;
+  b->stage_bytes = bytes;
+  b->h_off = reinterpret_cast<uint64_t *>(h);
+  b->h_sd = h + sizeof(uint64_t) * (nf + 1);
+  b->h_mv = h + hdr;
+  b->d_off = reinterpret_cast<uint64_t *>(dv);
+  b->d_sd = dv + sizeof(uint64_t) * (nf + 1);
+  b->d_mv = dv + hdr;
+  b->h_off[0] = 0;
+  b->cap_records = records;
 }
 
 #define PIPE_TRY(expr)                                               \
@@ -104,15 +141,15 @@ void free_batch(mtgpu_batch *b) {
     if (_e != hipSuccess) { rc = hip_fail(_e, #expr); goto bad; }    \
   } while (0)
 
-// (Re)allocate the staging block of a batch for `records` records; the batch must be idle and
-// empty (cap_frames is already set).  The new blocks are allocated BEFORE the old ones are let go:
-// when that fails the batch keeps its previous staging and capacity, so it stays usable.
+// Give a batch its OWN, larger staging block for `records` records (a frame larger than a whole batch); the
+// batch must be idle and empty.  The new blocks are allocated BEFORE the old ones are let go: when that fails
+// the batch keeps its previous staging and capacity, so it stays usable.  Its slice of the pipe's slab (if it
+// still used one) simply stays unused from then on.
 int alloc_records(mtgpu_batch *b, uint64_t records, bool inject_failure = false) {
   int rc = MT_OK;
   unsigned char *h_new = nullptr, *d_new = nullptr, *dev_view = nullptr;
-  const size_t nf = (size_t)b->cap_frames;
-  const size_t hdr = (sizeof(uint64_t) * (nf + 1) + (nf + 1) + 63u) & ~(size_t)63u;
-  const size_t bytes = hdr + (size_t)records * (size_t)b->rec_bytes + 64;
+  size_t hdr = 0;
+  const size_t bytes = stage_bytes_for(b->cap_frames, records, b->rec_bytes, &hdr);
   PIPE_TRY(hipHostMalloc(reinterpret_cast<void **>(&h_new), bytes, hipHostMallocDefault));
   if (inject_failure) { rc = fail(MT_ERR_NOMEM, "injected allocation failure (MTGPU_INJECT_GROW_FAIL)"); goto bad; }
   if (b->zero_copy) {
@@ -122,20 +159,12 @@ int alloc_records(mtgpu_batch *b, uint64_t records, bool inject_failure = false)
     PIPE_TRY(hipMalloc(reinterpret_cast<void **>(&d_new), bytes));
     dev_view = d_new;
   }
-  if (b->h_stage) (void)hipHostFree(b->h_stage);
-  if (b->d_stage) (void)hipFree(b->d_stage);
-  b->h_stage = h_new;
-  b->d_stage = d_new;
-  b->hdr_bytes = hdr;
-  b->stage_bytes = bytes;
-  b->h_off = reinterpret_cast<uint64_t *>(b->h_stage);
-  b->h_sd = b->h_stage + sizeof(uint64_t) * (nf + 1);
-  b->h_mv = b->h_stage + b->hdr_bytes;
-  b->d_off = reinterpret_cast<uint64_t *>(dev_view);
-  b->d_sd = dev_view + sizeof(uint64_t) * (nf + 1);
-  b->d_mv = dev_view + b->hdr_bytes;
-  b->h_off[0] = 0;
-  b->cap_records = records;
+  if (b->own_stage) {
+    if (b->h_stage) (void)hipHostFree(b->h_stage);
+    if (b->d_stage) (void)hipFree(b->d_stage);
+  }
+  b->own_stage = true;
+  set_stage(b, h_new, dev_view, d_new, hdr, bytes, records);
   return MT_OK;
 bad:
   if (h_new) (void)hipHostFree(h_new);
@@ -143,21 +172,27 @@ bad:
   return rc;
 }
 
-int alloc_batch(mtgpu_batch **out, uint64_t max_records, uint32_t max_frames, int rec_bytes, bool zero_copy) {
+// Batch i of a pipe: staging and result arrays are slices of the pipe's slabs at `off` (64-byte aligned).
+int alloc_batch(mtgpu_batch **out, mtgpu_pipe *p, size_t off, unsigned char *slab_dev_view, uint64_t max_records,
+                uint32_t max_frames) {
   int rc = MT_OK;
   mtgpu_batch *b = new (std::nothrow) mtgpu_batch();
   if (!b) return fail(MT_ERR_NOMEM, "out of host memory");
   b->cap_frames = max_frames;
-  b->rec_bytes = rec_bytes;
-  b->zero_copy = zero_copy;
-  if ((rc = alloc_records(b, max_records)) != MT_OK) { free_batch(b); return rc; }
+  b->rec_bytes = p->rec_bytes;
+  b->zero_copy = p->zero_copy;
   {
-    const size_t nf = (size_t)max_frames;
-    PIPE_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_pts), sizeof(double) * (nf + 1), hipHostMallocDefault));
-    PIPE_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_tag), sizeof(uint64_t) * (nf + 1), hipHostMallocDefault));
-    PIPE_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_flags), nf + 1, hipHostMallocDefault));
-    if (zero_copy) PIPE_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&b->d_flags), b->h_flags, 0));
-    else PIPE_TRY(hipMalloc(reinterpret_cast<void **>(&b->d_flags), nf + 1));
+    size_t hdr = 0;
+    const size_t sbytes = stage_bytes_for(max_frames, max_records, p->rec_bytes, &hdr);
+    const size_t nf = (size_t)max_frames + 1;
+    set_stage(b, p->h_slab + off, slab_dev_view + off, nullptr, hdr, sbytes, max_records);
+    unsigned char *aux = p->h_slab + off + sbytes;
+    b->aux_bytes = aux_bytes_for(max_frames);
+    b->h_pts = reinterpret_cast<double *>(aux);
+    b->h_tag = reinterpret_cast<uint64_t *>(aux + nf * sizeof(double));
+    b->h_flags = aux + nf * (sizeof(double) + sizeof(uint64_t));
+    // zero-copy: the kernel writes the flag bytes straight into the pinned slab; otherwise into the device slab
+    b->d_flags = slab_dev_view + off + sbytes + nf * (sizeof(double) + sizeof(uint64_t));
     PIPE_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
     // system-scope release at the event: the flag bytes a zero-copy scan wrote into pinned memory
     // are visible to the host thread that waits on it
@@ -206,12 +241,34 @@ int mtgpu_pipe_create_layout(mtgpu_ctx *ctx, uint64_t max_records_per_batch, uin
   if (const char *v = std::getenv("MTGPU_INJECT_SUBMIT_FAIL")) p->inject_submit_fail = std::atol(v);
   if (const char *v = std::getenv("MTGPU_INJECT_GROW_FAIL")) p->inject_grow_fail = std::atol(v) != 0;
   if (const char *v = std::getenv("MTGPU_INJECT_COLLECT_FAIL")) p->inject_collect_fail = std::atol(v);
-  for (int i = 0; i < n_buffers; ++i) {
-    mtgpu_batch *b = nullptr;
-    int rc = alloc_batch(&b, max_records_per_batch, max_frames_per_batch, p->rec_bytes, p->zero_copy);
-    if (rc != MT_OK) { mtgpu_pipe_destroy(p); return rc; }
-    b->owner = p;
-    p->bufs.push_back(b);
+  {
+    const size_t per = stage_bytes_for(max_frames_per_batch, max_records_per_batch, p->rec_bytes, nullptr) +
+                       aux_bytes_for(max_frames_per_batch);
+    p->slab_bytes = per * (size_t)n_buffers;
+    unsigned char *dev_view = nullptr;
+    e = hipHostMalloc(reinterpret_cast<void **>(&p->h_slab), p->slab_bytes, hipHostMallocDefault);
+    if (e != hipSuccess) { p->h_slab = nullptr; mtgpu_pipe_destroy(p); return hip_fail(e, "hipHostMalloc(pipe staging)"); }
+    if (p->zero_copy) {
+      e = hipHostGetDevicePointer(reinterpret_cast<void **>(&dev_view), p->h_slab, 0);
+      if (e != hipSuccess) { mtgpu_pipe_destroy(p); return hip_fail(e, "hipHostGetDevicePointer"); }
+    } else {
+      e = hipMalloc(reinterpret_cast<void **>(&p->d_slab), p->slab_bytes);
+      if (e != hipSuccess) { p->d_slab = nullptr; mtgpu_pipe_destroy(p); return hip_fail(e, "hipMalloc(pipe staging mirror)"); }
+      p->d_slab_bytes = p->slab_bytes;
+      dev_view = p->d_slab;
+    }
+    for (int i = 0; i < n_buffers; ++i) {
+      mtgpu_batch *b = nullptr;
+      int rc = alloc_batch(&b, p, per * (size_t)i, dev_view, max_records_per_batch, max_frames_per_batch);
+      if (rc != MT_OK) {
+        char keep[512];
+        std::snprintf(keep, sizeof keep, "%s", mtgpu_last_error());
+        mtgpu_pipe_destroy(p);
+        return fail(rc, "%s", keep);
+      }
+      b->owner = p;
+      p->bufs.push_back(b);
+    }
   }
   *out = p;
   return MT_OK;
@@ -220,7 +277,9 @@ int mtgpu_pipe_create_layout(mtgpu_ctx *ctx, uint64_t max_records_per_batch, uin
 void mtgpu_pipe_destroy(mtgpu_pipe *p) {
   if (!p) return;
   (void)hipSetDevice(mtgpu::ctx_device(p->ctx));
-  for (mtgpu_batch *b : p->bufs) free_batch(b);
+  for (mtgpu_batch *b : p->bufs) free_batch(b);      // drains every batch's stream first
+  if (p->h_slab) (void)hipHostFree(p->h_slab);
+  if (p->d_slab) (void)hipFree(p->d_slab);
   delete p;
 }
 
@@ -288,7 +347,7 @@ int mtgpu_pipe_submit(mtgpu_pipe *p, mtgpu_batch *b) {
   if (b->n_frames) {
     // one copy: offsets + has_sd header and the records that follow it (zero-copy: none at all)
     if (!b->zero_copy)
-      PIPE_TRY(hipMemcpyAsync(b->d_stage, b->h_stage, b->hdr_bytes + (size_t)b->n_records * (size_t)b->rec_bytes,
+      PIPE_TRY(hipMemcpyAsync(b->d_off, b->h_stage, b->hdr_bytes + (size_t)b->n_records * (size_t)b->rec_bytes,
                               hipMemcpyHostToDevice, st));
     if (p->inject_submit_fail > 0 && nth == p->inject_submit_fail) {
       rc = fail(MT_ERR_DEVICE, "injected submit failure (MTGPU_INJECT_SUBMIT_FAIL)");
@@ -360,11 +419,13 @@ int mtgpu_pipe_get_stats(mtgpu_pipe *p, mtgpu_pipe_stats *out) {
   if (!p || !out) return fail(MT_ERR_INVALID, "NULL argument");
   std::lock_guard<std::mutex> lock(p->mu);
   std::memset(out, 0, sizeof *out);
-  for (const mtgpu_batch *b : p->bufs) {
-    const size_t nf = (size_t)b->cap_frames + 1;
-    out->pinned_bytes += b->stage_bytes + nf * (sizeof(double) + sizeof(uint64_t) + 1);
-    if (!b->zero_copy) out->device_bytes += b->stage_bytes + nf;
-  }
+  out->pinned_bytes = p->slab_bytes;
+  out->device_bytes = p->d_slab_bytes;
+  for (const mtgpu_batch *b : p->bufs)
+    if (b->own_stage) {                              // grown for an oversize frame: its own blocks on top of the slabs
+      out->pinned_bytes += b->stage_bytes;
+      if (!b->zero_copy) out->device_bytes += b->stage_bytes;
+    }
   out->submits = (uint64_t)p->submits;
   out->n_buffers = (uint32_t)p->bufs.size();
   out->layout = (p->rec_bytes == MT_MV_BYTES ? MT_LAYOUT_AOS40 : MT_LAYOUT_COMPACT8) | (p->zero_copy ? MT_LAYOUT_ZERO_COPY : 0);

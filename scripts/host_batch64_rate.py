@@ -12,13 +12,16 @@ import bench  # noqa: E402
 
 exe = os.path.join(ROOT, "motion-estimated-video-trimmer_amd", "mtgpu_scan_file")
 out = {}
-for name, env in (("default (4 MiB compact zero-copy batches)", {}),
-                  ("1 MiB batches", {"MTGPU_BATCH_MB": "1"}),
-                  ("2 MiB batches", {"MTGPU_BATCH_MB": "2"}),
-                  ("8 MiB batches", {"MTGPU_BATCH_MB": "8"}),
-                  ("compact8 with copy commands", {"MTGPU_STAGING": "compact8"})):
+SETTINGS = (("default (4 MiB compact zero-copy batches)", {}),
+            ("1 MiB batches", {"MTGPU_BATCH_MB": "1"}),
+            ("2 MiB batches", {"MTGPU_BATCH_MB": "2"}),
+            ("8 MiB batches", {"MTGPU_BATCH_MB": "8"}),
+            ("compact8 with copy commands", {"MTGPU_STAGING": "compact8"}))
+if os.environ.get("ONLY_DEFAULT") == "1":
+    SETTINGS = SETTINGS[:1]
+for name, env in SETTINGS:
     r = bench.host_fed_batch64(exe, extra_env=env, configs=((64, 1), (16, 4), (4, 16)))
-    out[name] = {k: {kk: vv for kk, vv in v.items() if kk in ("frames_per_s_wall", "frames_per_s_steady", "wall_ms",
+    out[name] = {k: {kk: vv for kk, vv in v.items() if kk in ("frames_per_s_wall", "frames_per_s_steady", "wall_ms", "wall_ms_until_last_video", "setup_ms",
                                                               "worker_time_share", "held_on_one_device")}
                  for k, v in r.items() if isinstance(v, dict)}
     print(name, {k: (round(v.get("frames_per_s_steady") or 0), round(v["frames_per_s_wall"])) for k, v in out[name].items()},

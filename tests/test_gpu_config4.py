@@ -5,7 +5,7 @@ GPUs in place of CPU sets) -> per-stream FFmpegJob segment lists, at 64 streams 
 16 streams x 4 workers.  Every job is compared bit for bit with a Python transcription of the reference's
 worker loop driven by the oracle (chunks -> backward seek -> frame filter -> check_frame -> pool -> merge);
 still streams must produce no job; a damaged file must fail alone.  The batch summary line reports what
-64 x T workers hold on one device (contexts, pipes, HIP streams, pinned bytes).
+64 x T workers hold on one device (one shared context, 64 x T pipes, HIP streams, pinned bytes).
 """
 import json
 import os
@@ -117,11 +117,12 @@ def test_config4_64_streams_through_cpp_host_layer(streams64, streams, threads):
     assert (s["streams"], s["threads_per_stream"], s["videos"], s["failed"]) == (streams, threads, N_STREAMS, 0)
     assert s["jobs"] == len(jobs) == N_STREAMS - len(STILL)
     assert s["frames_scanned"] == sum(c[3] for c in cases.values())
-    # one context + one pinned pipe (3 staging batches, each with its stream and event) per worker thread
+    # ONE context for the whole process (same device, same parameter block: SharedContext) and one pinned pipe
+    # (3 staging batches, each with its stream and event, one pinned slab) per worker thread
     h = s["held"]
-    assert h["contexts"] == h["pipes"] == streams * threads
-    assert h["hip_streams"] == streams * threads * 4 and h["hip_events"] == streams * threads * 3
-    assert h["pinned_bytes"] >= streams * threads * 3 * (4 << 20)
+    assert h["contexts"] == 1 and h["mem_pools"] == 1 and h["pipes"] == streams * threads
+    assert h["hip_streams"] == streams * threads * 3 + 1 and h["hip_events"] == streams * threads * 3
+    assert streams * threads * 3 * (4 << 20) <= h["pinned_bytes"] <= streams * threads * 3 * (4 << 20) * 1.05
     print(f"\nconfig 4, {streams} streams x {threads} workers on one device: {s['frames_scanned']} frames in "
           f"{s['wall_us'] / 1e3:.0f} ms wall; held {h['contexts']} contexts, {h['hip_streams']} HIP streams, "
           f"{h['pinned_bytes'] / 2**20:.0f} MiB pinned, {h['device_bytes'] / 2**20:.1f} MiB device")
