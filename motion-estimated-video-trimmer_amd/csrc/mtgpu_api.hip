@@ -247,6 +247,7 @@ int make_plan(mtgpu_ctx *c, int lds_max, int cu_count) {
   }
   k.slices = 1;
   k.group = 1;
+  k.align_lines = env_int("MTGPU_ALIGN", 1) != 0 ? 1 : 0;     // experiments: 0 = streams start wherever the frame starts
   k.prefetch = env_int("MTGPU_PREFETCH", 1) != 0 ? 1 : 0;      // experiments: 0 switches the next-frame prefetch off
   c->group_request = env_int("MTGPU_GROUP", 0);
   c->min_lds_kb = env_int("MTGPU_MIN_LDS_KB", 0);

@@ -26,6 +26,7 @@ struct ScanK {
   int cnt_words;           // LDS counter words per workgroup ((band_rows + 2) * gw fields, padded to 4)
   int mask_rows;           // chunk_rows + 2
   int group;               // consecutive work items per workgroup (>= 1; > 1 only with slices == 1)
+  int align_lines;         // 40-byte records: peel < 16 head records so that the stream starts on a 128-byte line
   int prefetch;            // compact records, group > 1: issue the next frame's first step before this frame's cluster test
 };
 

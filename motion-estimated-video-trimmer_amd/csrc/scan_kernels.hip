@@ -279,6 +279,14 @@ __device__ __forceinline__ void vote(const MvFields m, const ScanK &k, int t0, i
   }
 }
 
+// Compact records: how many records at the start of a frame's array are scanned one by one so that the
+// 16-byte pair stream starts on a 128-byte line (align != 0; < 16 records) or at least on a 16-byte boundary.
+__device__ __forceinline__ unsigned long long compact_head(const unsigned char *base, unsigned long long n, int align) {
+  const unsigned long long a = (unsigned long long)(uintptr_t)base;
+  unsigned long long h = align ? (((0ull - a) & 127ull) >> 3) : ((a >> 3) & 1ull);
+  return h < n ? h : n;
+}
+
 // Compact records, several frames per workgroup (k.group > 1): the first streaming step of the NEXT frame is
 // issued while this frame's cluster test and the next frame's zeroing run.  Those phases touch only LDS (their
 // barriers wait on lgkmcnt, not on vector-memory loads), so the 4 x 16 bytes per lane stay in flight across
@@ -356,7 +364,24 @@ __device__ __forceinline__ void scan_item(
     if (band == 0) {                           // stream the records (HBM, exactly once per frame)
       if (trows > 0 && k.vec_need != 0u) {     // vec_need == 0: every cell is active anyway
         const unsigned char *base = mv + r0 * (unsigned long long)REC;
-        const unsigned long long n = r1 - r0;
+        unsigned long long n = r1 - r0;
+        if constexpr (REC == 40) {
+          // Line alignment.  A wave instruction of the loops below covers 64 records = 2560 bytes = exactly 20
+          // 128-byte lines IF the stream starts on a line; a frame that starts mid-line (real footage: every
+          // frame has its own record count) makes every instruction touch 21 lines, and the shared edge lines
+          // are fetched twice, by two different instructions (PMC, ragged 960x540 frames: 1.021 x the
+          // algorithmic bytes).  40 h = -start (mod 128) has a solution h < 16 whenever the start is 8-byte
+          // aligned (5 * 13 = 1 mod 16): the first h records go to lanes 0..h-1, the streams start on a line.
+          const unsigned int r = (unsigned int)((uintptr_t)base & 127u);
+          if (k.align_lines && (r & 7u) == 0u) {
+            unsigned long long h = (unsigned long long)((13u * ((16u - (r >> 3)) & 15u)) & 15u);
+            h = h < n ? h : n;
+            if ((unsigned long long)tid < h)
+              vote<FB, MODE, SPILL>(decode(load_rec<VAR, REC>(base + (unsigned long long)tid * REC)), k, t0, t1, cnt, sq);
+            base += h * (unsigned long long)REC;
+            n -= h;
+          }
+        }
         unsigned long long i = tid;
         constexpr unsigned long long STEP = (unsigned long long)UNROLL * BLOCK;
         constexpr unsigned long long LAST = (unsigned long long)(UNROLL - 1) * BLOCK;
@@ -364,15 +389,15 @@ __device__ __forceinline__ void scan_item(
           // Compact records: 16-byte loads of TWO records per lane (a wave instruction covers 1 KB),
           // UNROLL pairs in flight per lane — with 8-byte loads a CU keeps too few bytes in flight
           // to cover the HBM latency (measured 4.96 TB/s of compact bytes on 1080p).  The pair
-          // stream starts at the first 16-byte aligned record; lane 0 takes the odd ends.
-          const unsigned long long head = (n > 0 && ((unsigned long long)(uintptr_t)base & 8ull) != 0ull) ? 1ull : 0ull;
+          // stream starts at the first record on a 128-byte line (compact_head: up to 15 head records go to
+          // lanes 0..14, so that a wave instruction covers exactly 8 lines); lane 0 takes an odd last record.
+          const unsigned long long head = compact_head(base, n, k.align_lines);
           const unsigned char *pbase = base + head * 8ull;
           const unsigned long long np = (n - head) >> 1;            // pairs
-          if (tid == 0) {
-            if (head) vote<FB, MODE, SPILL>(decode(load_compact<VAR>(base)), k, t0, t1, cnt, sq);
-            if (((n - head) & 1ull) != 0ull)
-              vote<FB, MODE, SPILL>(decode(load_compact<VAR>(base + (n - 1ull) * 8ull)), k, t0, t1, cnt, sq);
-          }
+          if ((unsigned long long)tid < head)
+            vote<FB, MODE, SPILL>(decode(load_compact<VAR>(base + (unsigned long long)tid * 8ull)), k, t0, t1, cnt, sq);
+          if (tid == 0 && ((n - head) & 1ull) != 0ull)
+            vote<FB, MODE, SPILL>(decode(load_compact<VAR>(base + (n - 1ull) * 8ull)), k, t0, t1, cnt, sq);
           unsigned long long p = tid;
           if (ns.have) {                       // this frame's first step was issued during the previous frame's cluster test
             ns.have = false;
@@ -447,7 +472,7 @@ __device__ __forceinline__ void scan_item(
           const bool sdn = has_sd ? (has_sd[f + 1] != 0) : (b > a);
           const unsigned char *nb = mv + a * 8ull;
           const unsigned long long nn = b - a;
-          const unsigned long long nhead = (nn > 0 && ((unsigned long long)(uintptr_t)nb & 8ull) != 0ull) ? 1ull : 0ull;
+          const unsigned long long nhead = compact_head(nb, nn, k.align_lines);
           const unsigned long long nnp = (nn - nhead) >> 1;
           if (sdn && nnp >= (unsigned long long)UNROLL * BLOCK) {     // the whole first step lies inside the frame: uniform
             const unsigned char *npb = nb + nhead * 8ull;

@@ -40,6 +40,8 @@ VARIANTS_GROUP = [("auto", dict()), ("g1", dict(MTGPU_GROUP="1")), ("g2", dict(M
 VARIANTS_PREFETCH = [("g1", dict(MTGPU_GROUP="1")), ("g2/pf", dict(MTGPU_GROUP="2")), ("g2/nopf", dict(MTGPU_GROUP="2", MTGPU_PREFETCH="0")),
                      ("g4/pf", dict(MTGPU_GROUP="4")), ("g4/nopf", dict(MTGPU_GROUP="4", MTGPU_PREFETCH="0")),
                      ("g8/pf", dict(MTGPU_GROUP="8")), ("auto", dict())]
+# 40-byte records: streams start on a 128-byte line (head records peeled) or wherever the frame starts
+VARIANTS_ALIGN = [("aligned", dict()), ("unaligned", dict(MTGPU_ALIGN="0")), ("aligned2", dict()), ("unaligned2", dict(MTGPU_ALIGN="0"))]
 # workgroups per CU, capped through the LDS size of the launch (32-bit counters on a 1080p / 4K grid)
 VARIANTS_OCC = [("auto", dict()), ("lds40", dict(MTGPU_MIN_LDS_KB="40")), ("lds53", dict(MTGPU_MIN_LDS_KB="53")),
                 ("lds80", dict(MTGPU_MIN_LDS_KB="80")), ("lds160", dict(MTGPU_MIN_LDS_KB="160"))]
@@ -48,7 +50,7 @@ VARIANTS = [("fb32", dict(MTGPU_FORCE_FB="32")), ("fb2", dict(MTGPU_FORCE_FB="2"
             ("fb2/b512", dict(MTGPU_FORCE_FB="2", MTGPU_FORCE_BLOCK="512")),
             ("fb2/b1024", dict(MTGPU_FORCE_FB="2", MTGPU_FORCE_BLOCK="1024")),
             ("fb32/b1024", dict(MTGPU_FORCE_FB="32", MTGPU_FORCE_BLOCK="1024"))]
-FRAMES = {"1080p_dense8x8": 4096, "1080p_dense16": 16384, "4k_dense8x8": 1024, "4k_fine": 256}
+FRAMES = {"1080p_dense8x8": 4096, "1080p_dense16": 16384, "4k_dense8x8": 1024, "4k_fine": 256, "4k_fine_dense4": 1024}
 
 
 def main():
@@ -86,10 +88,10 @@ def main():
         scanners = []
         vset = {"fine": VARIANTS_FINE, "kernel": VARIANTS_KERNEL, "slices": VARIANTS_SLICES,
                 "bands": VARIANTS_BANDS, "tile": VARIANTS_TILE, "group": VARIANTS_GROUP, "occ": VARIANTS_OCC,
-                "prefetch": VARIANTS_PREFETCH}.get(os.environ.get("AB_SET"), VARIANTS)
+                "prefetch": VARIANTS_PREFETCH, "align": VARIANTS_ALIGN}.get(os.environ.get("AB_SET"), VARIANTS)
         for name, env in vset:
             for k in ("MTGPU_FORCE_FB", "MTGPU_FORCE_BLOCK", "MTGPU_FORCE_CHUNK", "MTGPU_VARIANT", "MTGPU_FORCE_SLICES",
-                      "MTGPU_BAND_LDS_KB", "MTGPU_MAX_TILE_KB", "MTGPU_GROUP", "MTGPU_MIN_LDS_KB", "MTGPU_PREFETCH"):
+                      "MTGPU_BAND_LDS_KB", "MTGPU_MAX_TILE_KB", "MTGPU_GROUP", "MTGPU_MIN_LDS_KB", "MTGPU_PREFETCH", "MTGPU_ALIGN"):
                 os.environ.pop(k, None)
             os.environ.update(env)
             try:

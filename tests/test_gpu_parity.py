@@ -953,6 +953,51 @@ def test_scan_frames_per_workgroup_grouping(gpu_scanner_factory, monkeypatch):
             assert np.array_equal(got, want), (w, g, "compact")
 
 
+def test_scan_line_aligned_streams(gpu_scanner_factory, monkeypatch):
+    """The record streams start on a 128-byte line: up to 15 head records of every frame are scanned one by one
+    (scan_kernels.hip, "Line alignment").  Frames whose first record sits at every possible offset inside a line
+    (40-byte records: 16 residues; compact: 16), frames shorter than their head, with the alignment on and off,
+    single-tile and banded plans, and voters placed exactly in the head and right behind it."""
+    import torch
+    rng = np.random.RandomState(5)
+    p = ob.params_from_config(1920, 1080, vectors_needed=2, clusters_needed=1)
+    frames, kinds = [], []
+    for i, n in enumerate([3, 0, 5, 1, 7, 2600, 2, 9, 11, 4, 13, 6, 1, 15, 8, 2601, 10, 12, 14, 16, 3000, 1, 1, 1, 17, 2, 2, 5000]):
+        mv = np.zeros(n, dtype=m.MV_DTYPE)
+        mv["dst_x"] = rng.randint(0, 1920, size=n)
+        mv["dst_y"] = rng.randint(0, 1080, size=n)
+        mv["src_x"], mv["src_y"] = mv["dst_x"] - 1, mv["dst_y"]
+        kind = "-"
+        if n >= 4:
+            kind = "AB"[i % 2]
+            cx, cy = int(rng.randint(2, 110)), int(rng.randint(6, 60))
+            pos = sorted({0, 1, min(n - 1, 15), n - 1} | ({16, 17} if n > 20 else set()))[:4]
+            while len(pos) < 4:
+                pos = sorted(set(pos) | {int(rng.randint(0, n))})
+            cells = [(cx, cy), (cx + 1, cy), (cx, cy), (cx + 1, cy)]
+            if kind == "B":
+                cells[3] = (cx + 7, cy + 2)                        # the second cell keeps one vote: inactive
+            for q, (gx, gy) in zip(pos, cells):
+                mv["dst_x"][q], mv["dst_y"][q] = gx * 16 + 8, gy * 16 + 8
+                mv["src_x"][q], mv["src_y"][q] = gx * 16 + 2, gy * 16 + 8
+        frames.append(mv)
+        kinds.append(kind)
+    b = m.FrameBatch.from_frames(frames)
+    assert len({(int(o) * 40) % 128 for o in b.frame_off[:-1]}) >= 12 and len({(int(o) * 8) % 128 for o in b.frame_off[:-1]}) >= 12
+    want = ob.scan_frames(p, b.mv, b.frame_off, b.has_sd)
+    assert want.tolist() == [1 if k == "A" else 0 for k in kinds]
+    rec = m.pack_records(b.mv)
+    d_rec = torch.from_numpy(rec.view(np.uint8).reshape(-1).copy()).cuda()
+    d_off = torch.from_numpy(b.frame_off.astype(np.int64)).cuda()
+    for align in ("1", "0"):
+        for fb in (None, 2, 8):                                     # 32-bit single tile, packed, banded (spill queue)
+            monkeypatch.setenv("MTGPU_ALIGN", align)
+            s = gpu_scanner_factory(m.ScanParams.from_config(1920, 1080, vectors_needed=2, clusters_needed=1), force_fb=fb)
+            monkeypatch.delenv("MTGPU_ALIGN")
+            assert np.array_equal(s.check_frames(b), want), (align, fb)
+            assert np.array_equal(s.check_frames_device_compact(d_rec, d_off, None).cpu().numpy(), want), (align, fb, "compact")
+
+
 @pytest.mark.parametrize("grid", ["1080p", "4k"])
 def test_compact_next_frame_prefetch(gpu_scanner_factory, monkeypatch, grid):
     """Compact records, several frames per workgroup: the first streaming step of the next frame is issued before
@@ -1008,9 +1053,11 @@ def test_compact_next_frame_prefetch(gpu_scanner_factory, monkeypatch, grid):
         for g, pf in ((2, 1), (3, 1), (4, 1), (8, 1), (25, 1), (64, 1), (4, 0), (1, 1)):
             monkeypatch.setenv("MTGPU_GROUP", str(g))
             monkeypatch.setenv("MTGPU_PREFETCH", str(pf))
+            monkeypatch.setenv("MTGPU_ALIGN", str(pf))            # without the prefetch also without the line alignment
             s = gpu_scanner_factory(m.ScanParams.from_config(w, h, **kw))
             monkeypatch.delenv("MTGPU_GROUP")
             monkeypatch.delenv("MTGPU_PREFETCH")
+            monkeypatch.delenv("MTGPU_ALIGN")
             assert s.plan["block_threads"] == block and s.plan["counter_bits"] == 32
             got = s.check_frames_device_compact(d_rec, d_off, d_sd).cpu().numpy()
             assert np.array_equal(got, want), (grid, kw, g, pf)
