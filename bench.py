@@ -3,7 +3,8 @@
 
 A step = one pass of the hot path over one device-resident batch of synthetic
 1080p AVMotionVector arrays (config "Synthetic 1080p MV arrays, 120x68 16px grid,
-30 fps stream", dense8x8 = 32 640 records = 1 305 600 B per P-frame):
+30 fps stream", dense8x8 = 32 640 records = 1 305 600 B per P-frame; default 16 384 frames = 21 GB
+per GPU and step):
     scan kernel (flags per frame)  ->  stream merge kernel (segments per stream)
     [N > 1: one RCCL all_gather of the per-GPU segment lists]
 Inputs are resident in HBM before the timed region.  Frames shard across ranks
@@ -45,7 +46,7 @@ OTHER_WORKLOADS = [("4k_dense8x8", "code_defaults", 1024, 40),
                    ("4k_fine_dense4", "shipped_env", 1024, 12),
                    # SURVEY.md 8(d) config 2, the other parameter set and the secondary density
                    # (one record per 16-px cell: 326 KB frames, several per workgroup)
-                   ("1080p_dense8x8", "shipped_env", 4096, 40),
+                   ("1080p_dense8x8", "shipped_env", 16384, 20),
                    ("1080p_dense16", "code_defaults", 16384, 40)]
 
 
@@ -54,7 +55,8 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--frames", type=int, default=4096, help="frames per GPU per step")
+    ap.add_argument("--frames", type=int, default=16384,
+                    help="frames per GPU per step (16384 dense8x8 1080p frames = 21 GB of records resident in HBM)")
     ap.add_argument("--streams", type=int, default=8, help="streams per GPU (frames split evenly)")
     ap.add_argument("--distinct", type=int, default=60, help="distinct generated frames per GPU (tiled)")
     ap.add_argument("--workload", default="1080p_dense8x8",
@@ -388,21 +390,22 @@ def other_workloads(dev, distinct):
         torch.cuda.empty_cache()
     # the headline workload once more as 8-byte compact records resident in HBM (the layout the
     # host dispatcher stages): 5x fewer bytes per frame, so frames/s rise; its own byte count is used
-    try:
-        w = build_workload("1080p_dense8x8", "code_defaults", 4096, min(distinct, 60), 1000, dev)
-        ref_ms = time_scan_only(w, 10)
-        k8, f8 = time_compact(w, 40)
-        assert np.array_equal(f8, w["d_flags"].cpu().numpy()), "compact flags differ from the 40-byte scan"
-        cbytes = 8 * w["n_records"] + 9 * w["frames"]
-        out.append({"workload": "synthetic 1080p_dense8x8 as COMPACT 8-byte records (src/dst int16 x4), 4096 frames",
-                    "frames_per_s": w["frames"] / (k8 * 1e-3), "kernel_ms": k8, "steps": 40,
-                    "achieved_GBps": cbytes / (k8 * 1e-3) / 1e9, "frac": cbytes / (k8 * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                    "bytes_per_launch": cbytes, "speedup_vs_40_byte_records": ref_ms / k8})
-        w["scanner"].close()
-        del w
-        torch.cuda.empty_cache()
-    except Exception as e:      # informational leg: never take the headline down
-        out.append({"workload": "1080p compact records", "error": repr(e)})
+    for cframes in (4096, 16384):
+        try:
+            w = build_workload("1080p_dense8x8", "code_defaults", cframes, min(distinct, 60), 1000, dev)
+            ref_ms = time_scan_only(w, 10)
+            k8, f8 = time_compact(w, 40)
+            assert np.array_equal(f8, w["d_flags"].cpu().numpy()), "compact flags differ from the 40-byte scan"
+            cbytes = 8 * w["n_records"] + 9 * w["frames"]
+            out.append({"workload": f"synthetic 1080p_dense8x8 as COMPACT 8-byte records (src/dst int16 x4), {cframes} frames",
+                        "frames_per_s": w["frames"] / (k8 * 1e-3), "kernel_ms": k8, "steps": 40,
+                        "achieved_GBps": cbytes / (k8 * 1e-3) / 1e9, "frac": cbytes / (k8 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "bytes_per_launch": cbytes, "speedup_vs_40_byte_records": ref_ms / k8})
+            w["scanner"].close()
+            del w
+            torch.cuda.empty_cache()
+        except Exception as e:      # informational leg: never take the headline down
+            out.append({"workload": f"1080p compact records, {cframes} frames", "error": repr(e)})
     return out
 
 
@@ -498,36 +501,54 @@ def _run_rank(a):
             for _ in range(2)] if world > 1 else None
     pending = [None, None]
     counter = [0]
+    # Two HIP streams, two sets of buffers: the stream-merge kernel (and, N > 1, the gather) of step i runs on its
+    # own stream while the scan of step i+1 already streams records on the launch stream — the merge is 8
+    # workgroups for ~6 us, there is no reason to hold 256 CUs back for it.  Events order the hand-offs:
+    # scan(k) -> merge(k) (flags[k] complete), merge(k) -> scan(k) two steps later (flags[k] / outputs[k] free).
+    scan_stream = torch.cuda.current_stream(dev)
+    merge_stream = torch.cuda.Stream(device=dev)
+    flag_bufs = [d_flags, torch.empty_like(d_flags)]
+    scan_done = [torch.cuda.Event() for _ in range(2)]
+    merge_done = [None, None]
 
     def step(i=None):
         k = counter[0] & 1
         counter[0] += 1
+        if merge_done[k] is not None:
+            scan_stream.wait_event(merge_done[k])
         if i is not None:
             ev0[i].record()
-        scanner.check_frames_device(d_mv, d_off, None, d_flags)
+        scanner.check_frames_device(d_mv, d_off, None, flag_bufs[k])
         if i is not None:
             ev1[i].record()
         if a.no_merge:
             return None
-        if pending[k] is not None:          # buffer set k is still being gathered (two steps ago)
-            pending[k].wait()
-            pending[k] = None
-        seg, res = scanner.merge_streams_device(d_flags, d_pts, d_soff, d_mp, True, SEG_CAP, out=outs[k])
-        if world > 1:
-            # the only exchange step of the path: per-GPU segment lists to every rank (RCCL over xGMI),
-            # asynchronous so that it overlaps the next step's scan
-            packed = mdist.pack_segment_lists(seg, res)
-            if a.backend == "nccl":
-                pending[k] = dist.all_gather_into_tensor(gath[k], packed, async_op=True)
-            else:       # rehearsal only: gloo moves the lists through host memory
-                mdist.gather_segment_lists(seg.cpu(), res.cpu(), out=gath[k])
+        scan_done[k].record(scan_stream)
+        with torch.cuda.stream(merge_stream):
+            merge_stream.wait_event(scan_done[k])
+            if pending[k] is not None:          # buffer set k is still being gathered (two steps ago)
+                pending[k].wait()
+                pending[k] = None
+            seg, res = scanner.merge_streams_device(flag_bufs[k], d_pts, d_soff, d_mp, True, SEG_CAP, out=outs[k])
+            if world > 1:
+                # the only exchange step of the path: per-GPU segment lists to every rank (RCCL over xGMI),
+                # asynchronous so that it overlaps the following scans
+                packed = mdist.pack_segment_lists(seg, res)
+                if a.backend == "nccl":
+                    pending[k] = dist.all_gather_into_tensor(gath[k], packed, async_op=True)
+                else:       # rehearsal only: gloo moves the lists through host memory
+                    mdist.gather_segment_lists(seg.cpu(), res.cpu(), out=gath[k])
+            merge_done[k] = torch.cuda.Event()
+            merge_done[k].record(merge_stream)
         return seg, res
 
     def finish():
-        for k in (0, 1):
-            if pending[k] is not None:
-                pending[k].wait()
-                pending[k] = None
+        with torch.cuda.stream(merge_stream):
+            for k in (0, 1):
+                if pending[k] is not None:
+                    pending[k].wait()
+                    pending[k] = None
+        merge_stream.synchronize()
 
     for _ in range(a.warmup):
         step()
@@ -642,6 +663,22 @@ def _run_rank(a):
     del out
 
 
+def cpu_quota():
+    """CPUs' worth of time the cgroup grants this process (cpu.max / cfs quota), or None if unlimited / unknown:
+    a box may show 256 hardware threads to a job that is allowed 16 of them."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
 def host_cpu_info():
     model = "unknown"
     try:
@@ -696,6 +733,8 @@ def cpu_baseline(params, mv, off, gpu_flags, budget_s, workload):
                      f"each on a thread-local copy of its share",
            "value_1core": res[1][0], "sample_1core": f"{res[1][1]} passes, {res[1][2]:.1f} s",
            "host_cpu": model, "host_cores_total": cores_total, "host_cores_usable": cores_usable,
+           "host_cpu_quota": cpu_quota(),     # CPUs of run time the cgroup allows (None: no limit): an all-thread leg
+                                              # beyond it is time-sliced, not parallel
            "GBps": {"1": res[1][0] * mv.nbytes / n / 1e9, str(share): v16 * mv.nbytes / n / 1e9}}
     if cores_usable in res and cores_usable != share:
         va, ra, da = res[cores_usable]

@@ -38,19 +38,28 @@ def test_soak_random_parity(gpu_scanner_factory):
                   clusters_needed=int(rng.choice([1, 2, 2, 3, 10])),
                   vertical_mask=float(rng.choice([0.0, 0.05, 0.2])))
         p = ob.params_from_config(w, h, **kw)
+        # frames per workgroup (next-frame prefetch on compact records), line alignment: knobs read at create time
+        knobs = {"MTGPU_GROUP": rng.choice(["", "", "2", "3", "8"]), "MTGPU_PREFETCH": rng.choice(["", "", "0"]),
+                 "MTGPU_ALIGN": rng.choice(["", "", "0"])}
+        for k_, v_ in knobs.items():
+            if v_:
+                os.environ[k_] = str(v_)
         try:
             s = gpu_scanner_factory(p, force_fb=forms[it % len(forms)])
         except m.MtgpuError as e:
             assert e.code == 2
             continue
+        finally:
+            for k_ in knobs:
+                os.environ.pop(k_, None)
         s.set_slices(int(rng.choice([0, 1, 2, 4, 8])))
         n_frames = int(rng.choice([3, 17, 64, 300]))
-        mv, off, sd = synth.random_frames(rng, n_frames, int(rng.choice([200, 3000, 20000])), w, h,
+        mv, off, sd = synth.random_frames(rng, n_frames, int(rng.choice([200, 3000, 20000, 20000 if n_frames > 64 else 60000])), w, h,
                                           hot=float(rng.choice([0.05, 0.5, 0.95])))
         want = ob.scan_frames(p, mv, off, sd, nthreads=8)
         for _ in range(2):                              # twice: warm caches, reused workspaces
             got = s.check_frames(m.FrameBatch(mv, off, None, sd))
-            assert np.array_equal(got, want), (seed, it, w, h, kw, s.plan)
+            assert np.array_equal(got, want), (seed, it, w, h, kw, s.plan, knobs)
         if it % 3 == 0:                                 # the 8-byte compact layout, device-resident
             import torch
             rec = m.pack_records(mv)
@@ -58,7 +67,7 @@ def test_soak_random_parity(gpu_scanner_factory):
                 torch.zeros(8, dtype=torch.uint8, device="cuda")
             got = s.check_frames_device_compact(d_rec[: len(rec) * 8], torch.from_numpy(off.astype(np.int64)).cuda(),
                                                 torch.from_numpy(sd).cuda()).cpu().numpy()
-            assert np.array_equal(got, want), ("compact", seed, it, w, h, kw, s.plan)
+            assert np.array_equal(got, want), ("compact", seed, it, w, h, kw, s.plan, knobs)
         if it % 5 == 0:                                 # the pinned pipe (zero-copy compact staging)
             pipe = m.ScanPipe(s, int(rng.choice([500, 5000, 50000])), int(rng.choice([1, 4, 32])), int(rng.choice([1, 2, 3])))
             for f in range(n_frames):
