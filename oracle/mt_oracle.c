@@ -215,8 +215,15 @@ int mto_scan_frames_mt(const mt_scan_params *p, const mt_mv *mv, const uint64_t 
  * thread scans its share `reps` times, and the wall time between the two barriers comes back in *seconds (thread
  * creation, the copies and the join are outside it).  flags = the results of the last pass. */
 typedef struct {
+  pthread_mutex_t mu;
+  pthread_cond_t cv;
+  int go;                        /* 0: wait, 1: run (the barrier is initialised), -1: give up */
+} mt_gate;
+
+typedef struct {
   mt_job j;
   int reps;
+  mt_gate *gate;
   pthread_barrier_t *bar;
   double *t0, *t1;
 } mt_bench_job;
@@ -230,6 +237,12 @@ static double now_sec(void) {
 static void *mt_bench_worker(void *arg) {
   mt_bench_job *b = (mt_bench_job *)arg;
   mt_job *j = &b->j;
+  /* nobody touches the barrier before the main thread knows that every party exists */
+  pthread_mutex_lock(&b->gate->mu);
+  while (b->gate->go == 0) pthread_cond_wait(&b->gate->cv, &b->gate->mu);
+  const int go = b->gate->go;
+  pthread_mutex_unlock(&b->gate->mu);
+  if (go < 0) { j->rc = MT_ERR_NOMEM; return NULL; }
   const uint32_t nf = j->f1 - j->f0;
   const uint64_t r0 = j->frame_off[j->f0], r1 = j->frame_off[j->f1];
   uint8_t *grid = (uint8_t *)malloc((size_t)j->p->grid_w * j->p->grid_h);
@@ -262,8 +275,12 @@ int mto_bench_scan(const mt_scan_params *p, const mt_mv *mv, const uint64_t *fra
   if ((uint32_t)nthreads > n_frames) nthreads = (int)n_frames;
   pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * nthreads);
   mt_bench_job *jobs = (mt_bench_job *)malloc(sizeof(mt_bench_job) * nthreads);
+  if (!th || !jobs) { free(th); free(jobs); return MT_ERR_NOMEM; }
+  mt_gate gate;
+  pthread_mutex_init(&gate.mu, NULL);
+  pthread_cond_init(&gate.cv, NULL);
+  gate.go = 0;
   pthread_barrier_t bar;
-  if (!th || !jobs || pthread_barrier_init(&bar, NULL, (unsigned)nthreads) != 0) { free(th); free(jobs); return MT_ERR_NOMEM; }
   double t0 = 0.0, t1 = 0.0;
   const uint64_t total = frame_off[n_frames] - frame_off[0];
   uint32_t f = 0;
@@ -274,23 +291,26 @@ int mto_bench_scan(const mt_scan_params *p, const mt_mv *mv, const uint64_t *fra
     else while (e < n_frames && frame_off[e + 1] <= target) ++e;
     if (e == f && f < n_frames && (n_frames - f) > (uint32_t)(nthreads - 1 - t)) e = f + 1;
     jobs[t].j = (mt_job){p, mv, frame_off, has_sd, flags, f, e, MT_OK};
-    jobs[t].reps = reps; jobs[t].bar = &bar; jobs[t].t0 = &t0; jobs[t].t1 = &t1;
+    jobs[t].reps = reps; jobs[t].gate = &gate; jobs[t].bar = &bar; jobs[t].t0 = &t0; jobs[t].t1 = &t1;
     f = e;
   }
   int started = 0, rc = MT_OK;
   for (; started < nthreads; ++started)
     if (pthread_create(&th[started], NULL, mt_bench_worker, &jobs[started]) != 0) break;
-  if (started < nthreads) {                          /* cannot run short of a full barrier party: give up cleanly */
-    for (int t = 0; t < started; ++t) pthread_cancel(th[t]);
-    for (int t = 0; t < started; ++t) pthread_join(th[t], NULL);
-    rc = MT_ERR_NOMEM;
-  } else {
-    for (int t = 0; t < nthreads; ++t) {
-      pthread_join(th[t], NULL);
-      if (jobs[t].j.rc != MT_OK) rc = jobs[t].j.rc;
-    }
+  /* every party exists: open the gate; a thread short (its frames would stay unscanned): everybody goes home */
+  const int all = started == nthreads && pthread_barrier_init(&bar, NULL, (unsigned)nthreads) == 0;
+  pthread_mutex_lock(&gate.mu);
+  gate.go = all ? 1 : -1;
+  pthread_cond_broadcast(&gate.cv);
+  pthread_mutex_unlock(&gate.mu);
+  for (int t = 0; t < started; ++t) {
+    pthread_join(th[t], NULL);
+    if (jobs[t].j.rc != MT_OK) rc = jobs[t].j.rc;
   }
-  pthread_barrier_destroy(&bar);
+  if (all) pthread_barrier_destroy(&bar);
+  else rc = MT_ERR_NOMEM;
+  pthread_mutex_destroy(&gate.mu);
+  pthread_cond_destroy(&gate.cv);
   free(th);
   free(jobs);
   *seconds = t1 - t0;
