@@ -1,0 +1,69 @@
+"""bench.py on the GPU box (`-m gpu`): the one-line JSON contract at N = 1, and the N > 1 control flow — rank
+processes started by bench.py itself, barrier + max-over-ranks timing, the exchange of segment lists, the `ranks`
+list — rehearsed with two gloo ranks on the one device this box has (RCCL refuses two ranks on one device; real
+multi-device RCCL runs only on the driver's 8-GPU node)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+QUICK = ["--steps", "4", "--warmup", "2", "--frames", "600", "--cpu-seconds", "0", "--no-others", "--no-host"]
+
+
+def _run(args):
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True,
+                       env=env, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]                    # exactly ONE line on stdout
+    return json.loads(lines[0])
+
+
+def _check_line(d, world, frames):
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["metric"].startswith("MV-scan frames/sec") and d["unit"] == "frames/s" and d["higher_is_better"] is True
+    assert d["n_gpus"] == world and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.05 < r["frac"] < 1.0
+    assert r["algorithmic_bytes_per_launch"] == d["config"]["bytes_per_step_per_gpu"]
+    # value = frames of ALL ranks / max-over-ranks time: consistent with ms_per_step
+    assert abs(d["value"] - frames * world / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    # the kernel cannot be slower than the whole step it is part of
+    assert r["kernel_ms"] <= d["ms_per_step"] * 1.05
+    assert 0 < d["motion_frames_in_batch"] < frames
+    assert len(d["ranks"]) == world and [x["rank"] for x in d["ranks"]] == list(range(world))
+    assert all(x["frames_scanned"] == frames * d["steps"] and x["kernel_ms"] > 0 for x in d["ranks"])
+
+
+def test_bench_line_single_gpu():
+    d = _run(QUICK)
+    _check_line(d, 1, 600)
+    assert d["distinct_devices"] == 1 and d["ranks"][0]["pci_bus_id"]
+    assert d["config"]["step"] == "scan + stream-merge kernels"
+    # traffic is either absent or labelled as replayed from the committed PMC summary
+    assert d["roofline"]["traffic"] is None or "replayed" in d["roofline"]["traffic_source"]
+
+
+def test_bench_two_ranks_rehearsal_gloo_same_device(tmp_path):
+    d = _run(["--gpus", "2", "--backend", "gloo", "--same-device"] + QUICK)
+    _check_line(d, 2, 600)
+    assert d["config"]["streams_total"] == 2 * d["config"]["streams_per_gpu"]
+    assert "all_gather" in d["config"]["step"]
+    assert d["distinct_devices"] == 1                              # --same-device: both ranks report the one bus id
+    assert d["cpu_baseline"] is None and d["other_workloads"] is None      # N > 1: the headline only
+    logs = [os.path.join(ROOT, "gpurun_out", f"bench_rank{r}.err") for r in (0, 1)]
+    logs = [p if os.path.exists(p) else os.path.join(ROOT, os.path.basename(p)) for p in logs]
+    for r, p in enumerate(logs):                                   # every rank left its own evidence
+        recs = [json.loads(ln) for ln in open(p)]
+        assert [x["stage"] for x in recs] == ["start", "timed"] and recs[1]["rank"] == r
