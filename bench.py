@@ -597,7 +597,10 @@ def _run_rank(a):
         with open(rank_log_path(rank), "a") as f:
             f.write(json.dumps({"stage": "timed", **ident}) + "\n")
         ranks = [None] * world
-        dist.all_gather_object(ranks, ident)
+        try:
+            dist.all_gather_object(ranks, ident)
+        except Exception as e:      # evidence only: the measured line must not be lost to it (each rank's log has its own record)
+            ranks = [dict(ident, note="all_gather_object failed: " + repr(e))]
 
     if rank == 0:
         total_frames = a.frames * world * a.steps
@@ -652,7 +655,7 @@ def _run_rank(a):
             "motion_frames_in_batch": int(flags_host.sum()),
             "ranks": ranks,
             "distinct_devices": len({(r or {}).get("pci_bus_id") or (r or {}).get("uuid") or i
-                                     for i, r in enumerate(ranks)}),
+                                     for i, r in enumerate(ranks)}) if len(ranks) == world else None,
         }
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     os.close(json_fd)
