@@ -68,7 +68,9 @@ def streams64(tmp_path_factory):
         cases[path] = (pooled, want_seg, want_res, scanned)
         paths.append(path)
         del frames
-    return str(d), paths, cases
+    yield str(d), paths, cases
+    import shutil
+    shutil.rmtree(str(d), ignore_errors=True)              # 6 GB of streams: do not leave them to pytest's retention
 
 
 def _chunk_starts(spec, frames, ticks, duration, chunk_sec):
