@@ -69,6 +69,10 @@ def parse(argv=None):
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --same-device rehearses the N>1 control flow on a 1-GPU box")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="rehearsal: run the distributed code path (process group, async all_gather of segment lists, "
+                         "barriers, max-over-ranks reduction, rank identity gather) even with ONE rank — executes the "
+                         "RCCL (`nccl`) branch on a 1-GPU box")
     return ap.parse_args(argv)
 
 
@@ -431,7 +435,7 @@ def device_identity(torch, dev, rank, local):
 def run_rank(a):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world == 1:
+    if world == 1 and not a.force_dist:
         return _run_rank(a)
     try:
         return _run_rank(a)
@@ -451,6 +455,12 @@ def _run_rank(a):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    multi = world > 1 or a.force_dist          # the distributed code path (normally: more than one rank)
+    if a.force_dist and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
     import torch
     import torch.distributed as dist
     import mvtrim_amd as m
@@ -463,7 +473,7 @@ def _run_rank(a):
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     ident = device_identity(torch, dev, rank, local)
-    if world > 1:
+    if multi:
         with open(rank_log_path(rank), "w") as f:
             f.write(json.dumps({"stage": "start", **ident}) + "\n")
         if a.backend == "nccl":
@@ -498,7 +508,7 @@ def _run_rank(a):
              torch.zeros((S, m.MERGE_RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev),
              torch.empty(2 * a.frames, dtype=torch.float64, device=dev)) for _ in range(2)]
     gath = [torch.empty((world, S, packed_w), dtype=torch.uint8, device=dev if a.backend == "nccl" else "cpu")
-            for _ in range(2)] if world > 1 else None
+            for _ in range(2)] if multi else None
     pending = [None, None]
     counter = [0]
     # Two HIP streams, two sets of buffers: the stream-merge kernel (and, N > 1, the gather) of step i runs on its
@@ -530,7 +540,7 @@ def _run_rank(a):
                 pending[k].wait()
                 pending[k] = None
             seg, res = scanner.merge_streams_device(flag_bufs[k], d_pts, d_soff, d_mp, True, SEG_CAP, out=outs[k])
-            if world > 1:
+            if multi:
                 # the only exchange step of the path: per-GPU segment lists to every rank (RCCL over xGMI),
                 # asynchronous so that it overlaps the following scans
                 packed = mdist.pack_segment_lists(seg, res)
@@ -554,7 +564,7 @@ def _run_rank(a):
         step()
     finish()
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -563,12 +573,12 @@ def _run_rank(a):
         out = step(i)
     finish()
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     dt_local = dt
-    if world > 1:
+    if multi:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -593,7 +603,7 @@ def _run_rank(a):
     ident.update({"frames_scanned": a.frames * a.steps, "kernel_ms": kern_ms, "wall_s": dt_local,
                   "motion_frames_in_batch": int(flags_host.sum()), "read_ceiling_GBps": read_ceiling})
     ranks = [ident]
-    if world > 1:
+    if multi:
         with open(rank_log_path(rank), "a") as f:
             f.write(json.dumps({"stage": "timed", **ident}) + "\n")
         ranks = [None] * world
@@ -647,7 +657,7 @@ def _run_rank(a):
                        "records_per_step_per_gpu": n_records,
                        "bytes_per_step_per_gpu": alg_bytes, "parallelism": f"frame-sharded x{world}",
                        "step": "scan kernel" if a.no_merge else "scan + stream-merge kernels" +
-                               (" + RCCL all_gather of segment lists" if world > 1 else "")},
+                               (" + RCCL all_gather of segment lists" if multi else "")},
             "roofline": roof,
             "cpu_baseline": cpu,
             "other_workloads": others,
@@ -659,7 +669,7 @@ def _run_rank(a):
         }
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     os.close(json_fd)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     scanner.close()

@@ -67,3 +67,14 @@ def test_bench_two_ranks_rehearsal_gloo_same_device(tmp_path):
     for r, p in enumerate(logs):                                   # every rank left its own evidence
         recs = [json.loads(ln) for ln in open(p)]
         assert [x["stage"] for x in recs] == ["start", "timed"] and recs[1]["rank"] == r
+
+
+def test_bench_rccl_branch_with_one_rank():
+    """The `nccl` (= RCCL) branch of the distributed path — process group bound to the device, asynchronous
+    all_gather_into_tensor of the packed segment lists issued from the merge stream, barriers, MAX all_reduce of the
+    wall time, all_gather_object of the rank identities — executed for real, with the one rank a 1-GPU box allows
+    (`--force-dist`).  Peers are the only thing missing; the driver's 8-GPU node supplies those."""
+    d = _run(["--force-dist"] + QUICK)
+    _check_line(d, 1, 600)
+    assert "RCCL all_gather" in d["config"]["step"]
+    assert d["distinct_devices"] == 1 and d["ranks"][0]["pci_bus_id"]
