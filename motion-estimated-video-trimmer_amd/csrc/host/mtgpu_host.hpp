@@ -78,11 +78,12 @@ struct Config {   // same variables, defaults and parse types as config.hpp:56-1
     }();
     return v;
   }
-  // not in the reference: pinned staging per batch of the host dispatcher, in MiB
-  // (default: 4 for the compact layout — 16 workers x 3 batches stay inside the host's L3, so the DMA
-  //  engine reads staging from cache — and 16 for the 40-byte layout)
+  // not in the reference: pinned staging per batch of the host dispatcher, in MiB.  Default 8 for the compact
+  // layout (round 3, 64 concurrent streams on one device: 8 MiB batches scan 10-50 % more frames/s than 4 MiB
+  // ones, 16 MiB another 10-30 % at 3 GB of pinned memory for 64 workers — profiles/r03_host_batch64_ab.json;
+  // one hot stream with 16 workers does not care) and 16 for the 40-byte layout.
   static int batch_mib() {
-    static int v = std::max(1, env_i("MTGPU_BATCH_MB", (staging_layout() & MT_LAYOUT_AOS40) ? 16 : 4));
+    static int v = std::max(1, env_i("MTGPU_BATCH_MB", (staging_layout() & MT_LAYOUT_AOS40) ? 16 : 8));
     return v;
   }
   // Parse everything the scan path reads, in the calling thread: a value that does not parse surfaces

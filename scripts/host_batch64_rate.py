@@ -19,6 +19,8 @@ SETTINGS = (("default (4 MiB compact zero-copy batches)", {}),
             ("compact8 with copy commands", {"MTGPU_STAGING": "compact8"}))
 if os.environ.get("ONLY_DEFAULT") == "1":
     SETTINGS = SETTINGS[:1]
+if os.environ.get("BATCH_AB") == "1":       # 4 vs 8 vs 16 MiB, twice, interleaved
+    SETTINGS = tuple((f"{mb} MiB batches, pass {k}", {"MTGPU_BATCH_MB": str(mb)}) for k in (1, 2) for mb in (4, 8, 16))
 for name, env in SETTINGS:
     r = bench.host_fed_batch64(exe, extra_env=env, configs=((64, 1), (16, 4), (4, 16)))
     out[name] = {k: {kk: vv for kk, vv in v.items() if kk in ("frames_per_s_wall", "frames_per_s_steady", "wall_ms", "wall_ms_until_last_video", "setup_ms",
