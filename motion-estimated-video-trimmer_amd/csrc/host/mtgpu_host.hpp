@@ -78,12 +78,13 @@ struct Config {   // same variables, defaults and parse types as config.hpp:56-1
     }();
     return v;
   }
-  // not in the reference: pinned staging per batch of the host dispatcher, in MiB.  Default 8 for the compact
-  // layout (round 3, 64 concurrent streams on one device: 8 MiB batches scan 10-50 % more frames/s than 4 MiB
-  // ones, 16 MiB another 10-30 % at 3 GB of pinned memory for 64 workers — profiles/r03_host_batch64_ab.json;
-  // one hot stream with 16 workers does not care) and 16 for the 40-byte layout.
+  // not in the reference: pinned staging per batch of the host dispatcher, in MiB.  Default 16 for either layout
+  // (round 3, 64 concurrent streams on one device, steady-state window over 614 000 frames per run: 16 MiB batches
+  // scan 4-24 % (64 x 1 workers), 45-58 % (16 x 4) and 45 % (4 x 16) more frames/s than 4 MiB ones — a batch costs a
+  // launch, an event and a wake-up whatever its size — at 48 MiB of pinned memory per worker;
+  // profiles/r03_host_batch64_ab2.json.  One hot stream with 16 workers does not care.)
   static int batch_mib() {
-    static int v = std::max(1, env_i("MTGPU_BATCH_MB", (staging_layout() & MT_LAYOUT_AOS40) ? 16 : 8));
+    static int v = std::max(1, env_i("MTGPU_BATCH_MB", 16));
     return v;
   }
   // Parse everything the scan path reads, in the calling thread: a value that does not parse surfaces
@@ -511,6 +512,8 @@ struct PipelineResult {
   long seek_us = 0, decode_us = 0, analyze_us = 0;   // summed over workers, as pipeline.cpp:229-233
   long init_us = 0, scan_wall_us = 0;                // worker init (summed) / wall time of the scan phase
   long scan_work_us = 0;                             // wall time from "every worker initialised" to the last result
+  long long work_begin_abs_us = 0, work_end_abs_us = 0;   // those two instants on the steady clock (process_batch
+                                                          // needs them to find the window in which ANY video was scanned)
   long copy_us = 0, submit_us = 0, wait_us = 0;      // parts of analyze_us (summed over workers): copy-out into pinned
                                                      // staging, submit calls, waiting for the GPU
   std::string error;
@@ -621,6 +624,8 @@ int run_scan_pipeline(MakeSource make_source, int num_threads, PipelineResult &o
     const auto wall1 = std::chrono::high_resolution_clock::now();
     out.scan_wall_us = (long)std::chrono::duration_cast<std::chrono::microseconds>(wall1 - wall0).count();
     out.scan_work_us = (long)std::chrono::duration_cast<std::chrono::microseconds>(wall1 - work0).count();
+    out.work_begin_abs_us = (long long)std::chrono::duration_cast<std::chrono::microseconds>(work0.time_since_epoch()).count();
+    out.work_end_abs_us = (long long)std::chrono::duration_cast<std::chrono::microseconds>(wall1.time_since_epoch()).count();
   }
   if (!out.error.empty()) return 1;
   out.timestamps = results.extract();
@@ -678,6 +683,10 @@ struct BatchSummary {   // what a whole process_batch run did and what it held (
   uint64_t frames_scanned = 0;
   long wall_us = 0;                                        // first stream thread started -> last one finished (teardown included)
   long scan_wall_us = 0;                                   // ... -> last video finished (contexts / pipes still alive)
+  long scan_window_us = 0;                                 // first worker of any video ready -> last result of any video:
+                                                           // the steady-state window (pipes persist from video to video, so
+                                                           // only each stream's first video pays set-up, before this window)
+  long long window_begin_abs_us = 0, window_end_abs_us = 0;
   long init_us = 0, decode_us = 0, analyze_us = 0, copy_us = 0, submit_us = 0, wait_us = 0;   // summed over all workers
   Resources held;                                          // summed over the S x T backends alive at the end
 };
@@ -749,6 +758,10 @@ int process_batch(const std::vector<std::string> &files, const std::string &outp
           std::lock_guard<std::mutex> l(s_mu);
           const PipelineResult &r = job.result;
           sum.frames_scanned += r.frames_scanned;
+          if (rc == 0 && r.work_end_abs_us > 0) {
+            if (sum.window_begin_abs_us == 0 || r.work_begin_abs_us < sum.window_begin_abs_us) sum.window_begin_abs_us = r.work_begin_abs_us;
+            if (r.work_end_abs_us > sum.window_end_abs_us) sum.window_end_abs_us = r.work_end_abs_us;
+          }
           sum.init_us += r.init_us; sum.decode_us += r.decode_us; sum.analyze_us += r.analyze_us;
           sum.copy_us += r.copy_us; sum.submit_us += r.submit_us; sum.wait_us += r.wait_us;
         }
@@ -767,6 +780,7 @@ int process_batch(const std::vector<std::string> &files, const std::string &outp
   for (auto &t : streams) t.join();
   jobs.finish();
   sum.failed = (size_t)failed.load();
+  sum.scan_window_us = (long)(sum.window_end_abs_us - sum.window_begin_abs_us);
   sum.wall_us = (long)std::chrono::duration_cast<std::chrono::microseconds>(
                     std::chrono::high_resolution_clock::now() - wall0).count();
   if (summary) *summary = sum;
