@@ -75,7 +75,7 @@ int mtgpu_get_params(const mtgpu_ctx *ctx, mt_scan_params *out);
  * batch scanned so far; slice tiles; the merge workspace: 24 bytes per timestamp) comes from a
  * private stream-ordered pool that KEEPS freed blocks until mtgpu_trim or mtgpu_destroy, so that a
  * steady stream of batches never re-maps memory.  A host that scans one huge batch
- * and then idles should call mtgpu_trim; the C++ host layer does so between the videos of a batch.
+ * and then idles should call mtgpu_trim; the C++ host layer does so between videos when a context has one user.
  */
 typedef struct mtgpu_ctx_stats {
   uint64_t staging_device_bytes;  /* grow-only device buffers of the HOST-pointer entry points   */

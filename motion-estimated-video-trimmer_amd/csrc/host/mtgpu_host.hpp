@@ -325,9 +325,10 @@ class GpuBackend {
     return r;
   }
   // between two videos: hand the scratch pool's cached blocks back (the spill queue of a banded plan is
-  // 4 bytes per record of the largest batch ever scanned); only unused blocks go, other workers' launches
-  // on the shared context are not disturbed
-  void trim() { if (shared_) (void)mtgpu_trim(shared_->get()); }
+  // 4 bytes per record of the largest batch ever scanned) — but only when no other worker shares the context:
+  // while others scan, their next launches would map the same scratch again at once, and the pool is per
+  // device now, not per worker, so what it retains no longer multiplies with N x S
+  void trim() { if (shared_ && shared_.use_count() == 1) (void)mtgpu_trim(shared_->get()); }
   // cfg/grid derivation of MotionScanner::initialize (motion_scanner.cpp:184-199) + device setup;
   // a backend already set up for this frame size and device is reused as it is.
   bool ensure(int width, int height, int device, uint64_t batch_records, uint32_t batch_frames, int n_buffers,
