@@ -221,6 +221,18 @@ class MotionScanner:
         """Workgroups per frame: 0 = automatic (default), or 1 / 2 / 4 / 8.  Never changes results."""
         check(self._lib.mtgpu_set_slices(self._ctx, int(slices)))
 
+    def stats(self) -> dict:
+        """What the context holds on the device (mtgpu_get_stats): staging of the host-pointer entry points,
+        the scratch pool's reserved bytes now and at its high-water mark."""
+        from ._abi import CtxStatsC
+        st = CtxStatsC()
+        check(self._lib.mtgpu_get_stats(self._ctx, C.byref(st)))
+        return {n: getattr(st, n) for n, _ in CtxStatsC._fields_}
+
+    def trim(self):
+        """Hand the scratch pool's unused blocks back to the device (mtgpu_trim)."""
+        check(self._lib.mtgpu_trim(self._ctx))
+
     # ---------------------------------------------------------------- scan
     def check_frames(self, batch: FrameBatch) -> np.ndarray:
         """check_frame() for every frame of a host batch -> uint8 flags [F]."""

@@ -1069,6 +1069,34 @@ def test_compact_next_frame_prefetch(gpu_scanner_factory, monkeypatch, grid):
             assert np.array_equal(got, want[lo:hi]), (grid, kw, g, pf, "window")
 
 
+def test_scratch_pool_stats_and_trim(gpu_scanner_factory):
+    """the per-context scratch pool kept every block until mtgpu_destroy.  A banded plan's spill queue is
+    4 bytes per record of the batch: it shows up in mtgpu_get_stats, mtgpu_trim hands it back, and the next scan
+    simply maps scratch again (same flags)."""
+    import torch
+    p, s = _fine_shipped_env_scanner(gpu_scanner_factory)            # 960x540, 2 spill bands
+    spec = synth.spec_4k_fine_dense(seed=3)
+    spec.events = [synth.Event(1, 4, 400, 300, 4, 4, 7, 1)]
+    mv, off, pts, sd = synth.gen_stream(spec, 6)
+    want = ob.scan_frames(p, mv, off, sd)
+    d_mv = torch.from_numpy(mv.view(np.uint8).copy()).cuda()
+    d_off = torch.from_numpy(off.astype(np.int64)).cuda()
+    before = s.stats()
+    assert before["private_pool"] == 1 and before["hip_streams"] == 1
+    got = s.check_frames_device(d_mv, d_off, None).cpu().numpy()
+    assert np.array_equal(got, want) and 0 < want.sum() < 6
+    torch.cuda.synchronize()
+    held = s.stats()
+    assert held["pool_reserved_high"] >= 4 * len(mv) and held["pool_reserved_bytes"] >= 4 * len(mv)     # the queue stays cached
+    s.trim()
+    after = s.stats()
+    assert after["pool_reserved_bytes"] < held["pool_reserved_bytes"] and after["pool_reserved_high"] >= held["pool_reserved_high"]
+    assert np.array_equal(s.check_frames_device(d_mv, d_off, None).cpu().numpy(), want)
+    # the host-pointer entry points keep grow-only staging of their own: reported separately
+    assert np.array_equal(s.check_frames(m.FrameBatch(mv, off, None, sd)), want)
+    assert s.stats()["staging_device_bytes"] >= 40 * len(mv)
+
+
 def test_plain_c_example(tmp_path):
     """examples/scan_example.c: the ABI consumed from plain C (gcc), end to end on the GPU."""
     import os
