@@ -39,7 +39,9 @@ HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; ~6
 
 # (workload, params, frames, steps): scanned after the headline at N=1 and reported under
 # "other_workloads" (north_star: frames/s on 1080p AND 4K; config 5 = the 960x540 fine grid).
-OTHER_WORKLOADS = [("4k_dense8x8", "code_defaults", 1024, 40),
+# Every leg scans about 21 GB per launch, like the headline (a launch's ramp and tail are then the same small share
+# of every leg; rounds 1-2 used 5 GB for the 16-px grids).
+OTHER_WORKLOADS = [("4k_dense8x8", "code_defaults", 4096, 20),
                    ("4k_fine", "code_defaults", 1024, 12),
                    # shipped env (VECTORS_NEEDED 4) on the fine grid needs >= 4 records per 4x4 block somewhere to
                    # ever say yes: the dense4 density (4 per block inside moving regions, ragged frames)
@@ -47,7 +49,7 @@ OTHER_WORKLOADS = [("4k_dense8x8", "code_defaults", 1024, 40),
                    # SURVEY.md 8(d) config 2, the other parameter set and the secondary density
                    # (one record per 16-px cell: 326 KB frames, several per workgroup)
                    ("1080p_dense8x8", "shipped_env", 16384, 20),
-                   ("1080p_dense16", "code_defaults", 16384, 40)]
+                   ("1080p_dense16", "code_defaults", 65536, 20)]
 
 
 def parse(argv=None):
