@@ -98,3 +98,24 @@ def test_bench_gpus_n_launches_n_ranks_itself(tmp_path):
     assert bench.launch_ranks(bench.parse(["--gpus", "3"]), ["--gpus", "3"], environ=dict(os.environ), popen=probe_popen) == 0
     assert bench.launch_ranks(bench.parse(["--gpus", "3"]), ["--gpus", "3"],
                               environ=dict(os.environ, FAIL_RANK="1"), popen=probe_popen) == 3
+
+
+def test_bench_helpers_traffic_quota_and_rank_logs():
+    """CPU-tier pieces of the bench line: `traffic` is replayed from the committed PMC summary and labelled as such
+    for EVERY leg the default run reports; the cgroup CPU quota is a positive number or None; rank logs are named
+    per rank."""
+    sys.path.insert(0, ROOT)
+    import bench
+    a = bench.parse([])
+    t, src = bench.replayed_traffic(a.workload, a.params, a.frames)
+    assert t and 1.0 <= t / (40 * 15837 * 32640 + 9 * 16384) < 1.001        # 16 384 frames: 15 837 P-frames x 32 640 records
+    assert src.startswith("replayed, not measured in this run") and "pmc_traffic.json" in src and "round 3" in src
+    for (wl, pn, frames, _steps) in bench.OTHER_WORKLOADS:
+        t, src = bench.replayed_traffic(wl, pn, frames)
+        assert t and "replayed" in src, (wl, pn, frames)
+    assert bench.replayed_traffic("1080p_dense8x8", "code_defaults", 12345) == (None, None)
+    q = bench.cpu_quota()
+    assert q is None or q > 0
+    assert os.path.basename(bench.rank_log_path(3)) == "bench_rank3.err"
+    model, total, usable = bench.host_cpu_info()
+    assert total >= usable >= 1 and isinstance(model, str)
