@@ -212,7 +212,9 @@ int mtgpu_merge_streams_device(mtgpu_ctx *ctx, const uint8_t *d_flags, const dou
  * collected in submission order.  `n_buffers` batches bound the memory in flight
  * (back-pressure: acquire fails with MT_ERR_BUSY until a batch is collected and released).
  * One pipe per decoder thread — the reference's one-MotionScanner-per-worker model
- * (src/pipeline.cpp:186-197); pipes of one context may be used concurrently.
+ * (src/pipeline.cpp:186-197); pipes of one context may be used concurrently, so N worker threads need
+ * N pipes but only ONE context per device.  A pipe's staging is one pinned allocation (plus one device
+ * allocation without MT_LAYOUT_ZERO_COPY) carved into its n_buffers batches.
  */
 typedef struct mtgpu_pipe mtgpu_pipe;
 typedef struct mtgpu_batch mtgpu_batch;
@@ -231,7 +233,8 @@ int mtgpu_pipe_create_layout(mtgpu_ctx *ctx, uint64_t max_records_per_batch, uin
                              int n_buffers, int layout, mtgpu_pipe **out);
 void mtgpu_pipe_destroy(mtgpu_pipe *pipe);
 
-/* A free staging batch to fill, or MT_ERR_BUSY if all are in flight / held. */
+/* A free staging batch to fill, or MT_ERR_BUSY if all are in flight / held (MT_ERR_DEVICE if every batch
+ * of the pipe was retired after failed collects: destroy the pipe). */
 int mtgpu_pipe_acquire(mtgpu_pipe *pipe, mtgpu_batch **out);
 
 /* Append one decoded frame: copies n_bytes / 40 records (trailing bytes ignored, :226).
