@@ -151,6 +151,9 @@ def launch_ranks(a, argv, environ=None, popen=subprocess.Popen):
 
 def make_spec(workload, seed):
     from mvtrim_amd import synth
+    if workload in ("480p_dense16", "480p_dense8x8", "720p_dense16", "720p_dense8x8"):     # small frames (scripts only)
+        w, h = (640, 480) if workload.startswith("480p") else (1280, 720)
+        return synth.StreamSpec(w, h, 16, 2 if workload.endswith("8x8") else 1, seed=seed), (w, h, {})
     if workload == "1080p_dense8x8":
         return synth.spec_1080p(seed=seed, sub=2), (1920, 1080, {})
     if workload == "1080p_dense16":

@@ -294,7 +294,11 @@ int choose_group(const mtgpu_ctx *c, uint64_t n_records, uint32_t n_frames, int 
     const uint64_t avg = n_records * (uint64_t)rec_bytes / n_frames;
     const uint64_t cus = (uint64_t)(c->plan.cu_count > 0 ? c->plan.cu_count : 256);
     g = 1;
-    while (g < 8 && avg * (uint64_t)(2 * g) <= (1ull << 18) && (uint64_t)n_frames >= cus * 8ull * (uint64_t)(2 * g)) g *= 2;
+    // round 3, 40-byte records at 21 GB per launch: 48 KB frames (480p, one record per cell) 5.98 / 6.28 / 6.48 /
+    // 6.70 TB/s with 1 / 2 / 4 / 8 frames per workgroup, 144 KB frames (720p) 7.01 / 7.15 / 7.19 / 7.13, 192 KB
+    // frames (480p dense8x8) 7.22 / 7.08 / 7.04: frames up to ~160 KB are grouped up to ~600 KB per workgroup
+    if (avg <= 160ull * 1024ull)
+      while (g < 8 && avg * (uint64_t)(2 * g) <= 600ull * 1024ull && (uint64_t)n_frames >= cus * 8ull * (uint64_t)(2 * g)) g *= 2;
     // Compact records on a tile that leaves ONE workgroup per CU (4K: 124 KB of 32-bit counters): nothing overlaps
     // that workgroup's zeroing and cluster test (5 of 38 us per ~1 MB frame), so it scans 2-4 frames in a row
     // and issues the next frame's first streaming step before its cluster test (scan_kernels.hip, NextStep).
