@@ -419,10 +419,23 @@ __device__ __forceinline__ void scan_item(
               vote<FB, MODE, SPILL>(decode((u32x2){d[u].z, d[u].w}), k, t0, t1, cnt, sq);
             }
           }
-          for (; p < np; p += BLOCK) {
-            const u32x4 d = load_pair<VAR>(pbase + p * 16ull);
-            vote<FB, MODE, SPILL>(decode((u32x2){d.x, d.y}), k, t0, t1, cnt, sq);
-            vote<FB, MODE, SPILL>(decode((u32x2){d.z, d.w}), k, t0, t1, cnt, sq);
+          {
+            // the rest (fewer than one step: at most UNROLL pairs per lane), every load issued before the first
+            // vote — a frame smaller than one step (SD streams) costs ONE memory round trip, not one per pair
+            u32x4 d[UNROLL];
+            bool ok[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+              const unsigned long long q = p + (unsigned long long)u * BLOCK;
+              ok[u] = q < np;
+              d[u] = ok[u] ? load_pair<VAR>(pbase + q * 16ull) : (u32x4){0u, 0u, 0u, 0u};
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u)
+              if (ok[u]) {
+                vote<FB, MODE, SPILL>(decode((u32x2){d[u].x, d[u].y}), k, t0, t1, cnt, sq);
+                vote<FB, MODE, SPILL>(decode((u32x2){d[u].z, d[u].w}), k, t0, t1, cnt, sq);
+              }
           }
           i = n;                                                    // nothing left for the generic tail loop
         } else if constexpr ((VAR & 8) != 0) {
@@ -461,7 +474,22 @@ __device__ __forceinline__ void scan_item(
             for (int u = 0; u < UNROLL; ++u) vote<FB, MODE, SPILL>(decode(d[u]), k, t0, t1, cnt, sq);
           }
         }
-        for (; i < n; i += BLOCK) vote<FB, MODE, SPILL>(decode(load_rec<VAR, REC>(base + i * REC)), k, t0, t1, cnt, sq);
+        if (i < n) {
+          // the rest (fewer than one step: at most UNROLL records per lane), every load issued before the first
+          // vote — a frame smaller than one step (SD streams) costs ONE memory round trip, not one per record
+          constexpr int TU = UNROLL > 4 ? UNROLL : 4;
+          Raw d[TU];
+          bool ok[TU];
+#pragma unroll
+          for (int u = 0; u < TU; ++u) {
+            const unsigned long long q = i + (unsigned long long)u * BLOCK;
+            ok[u] = q < n;
+            if (ok[u]) d[u] = load_rec<VAR, REC>(base + q * REC);
+          }
+#pragma unroll
+          for (int u = 0; u < TU; ++u)
+            if (ok[u]) vote<FB, MODE, SPILL>(decode(d[u]), k, t0, t1, cnt, sq);
+        }
       }
       if constexpr (REC == 8 && !SPILL) {
         if (has_next && k.slices == 1 && k.vec_need != 0u && trows > 0) {   // exactly when the next frame's phase 1 runs
