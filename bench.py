@@ -49,7 +49,10 @@ OTHER_WORKLOADS = [("4k_dense8x8", "code_defaults", 4096, 20),
                    # SURVEY.md 8(d) config 2, the other parameter set and the secondary density
                    # (one record per 16-px cell: 326 KB frames, several per workgroup)
                    ("1080p_dense8x8", "shipped_env", 16384, 20),
-                   ("1080p_dense16", "code_defaults", 65536, 20)]
+                   ("1080p_dense16", "code_defaults", 65536, 20),
+                   # SD CCTV stream, one record per 16-px cell: 1200 records = 48 KB per frame, smaller than one
+                   # streaming step of a workgroup — eight frames per workgroup, the whole frame in one round trip
+                   ("480p_dense16", "code_defaults", 262144, 20)]
 
 
 def parse(argv=None):
@@ -62,7 +65,8 @@ def parse(argv=None):
     ap.add_argument("--streams", type=int, default=8, help="streams per GPU (frames split evenly)")
     ap.add_argument("--distinct", type=int, default=60, help="distinct generated frames per GPU (tiled)")
     ap.add_argument("--workload", default="1080p_dense8x8",
-                    choices=["1080p_dense8x8", "1080p_dense16", "4k_dense8x8", "4k_fine", "4k_fine_dense4"])
+                    choices=["1080p_dense8x8", "1080p_dense16", "4k_dense8x8", "4k_fine", "4k_fine_dense4", "480p_dense16",
+                             "720p_dense16", "480p_dense8x8", "720p_dense8x8"])
     ap.add_argument("--params", default="code_defaults", choices=["code_defaults", "shipped_env"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample budget (0 = skip)")
     ap.add_argument("--no-merge", action="store_true", help="time the scan kernel alone")
@@ -151,7 +155,7 @@ def launch_ranks(a, argv, environ=None, popen=subprocess.Popen):
 
 def make_spec(workload, seed):
     from mvtrim_amd import synth
-    if workload in ("480p_dense16", "480p_dense8x8", "720p_dense16", "720p_dense8x8"):     # small frames (scripts only)
+    if workload in ("480p_dense16", "480p_dense8x8", "720p_dense16", "720p_dense8x8"):     # SD / 720p streams
         w, h = (640, 480) if workload.startswith("480p") else (1280, 720)
         return synth.StreamSpec(w, h, 16, 2 if workload.endswith("8x8") else 1, seed=seed), (w, h, {})
     if workload == "1080p_dense8x8":

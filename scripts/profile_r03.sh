@@ -13,7 +13,7 @@ run() { name=$1; shift; echo "== $name $(date +%T)"; "$@" > $O/$name.log 2>&1 ||
 rm -f $O/r03_pmc_traffic.json
 # workload params frames steps
 LEGS="1080p_dense8x8:code_defaults:16384:20 1080p_dense8x8:shipped_env:16384:20 1080p_dense8x8:code_defaults:4096:20 4k_dense8x8:code_defaults:4096:20 4k_dense8x8:code_defaults:1024:20 4k_fine:code_defaults:1024:8 \
-4k_fine_dense4:shipped_env:1024:8 1080p_dense8x8:shipped_env:4096:20 1080p_dense16:code_defaults:65536:20 1080p_dense16:code_defaults:16384:20"
+4k_fine_dense4:shipped_env:1024:8 1080p_dense8x8:shipped_env:4096:20 1080p_dense16:code_defaults:65536:20 1080p_dense16:code_defaults:16384:20 480p_dense16:code_defaults:262144:20"
 for leg in ${LEGS_OVERRIDE:-$LEGS}; do
   IFS=: read wl pn fr st <<< "$leg"
   tag=r03_${wl}_${pn}
