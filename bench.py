@@ -65,7 +65,7 @@ def parse(argv=None):
     ap.add_argument("--streams", type=int, default=8, help="streams per GPU (frames split evenly)")
     ap.add_argument("--distinct", type=int, default=60, help="distinct generated frames per GPU (tiled)")
     ap.add_argument("--workload", default="1080p_dense8x8",
-                    choices=["1080p_dense8x8", "1080p_dense16", "4k_dense8x8", "4k_fine", "4k_fine_dense4", "480p_dense16",
+                    choices=["1080p_dense8x8", "1080p_dense16", "4k_dense8x8", "4k_dense16", "4k_fine", "4k_fine_dense4", "480p_dense16",
                              "720p_dense16", "480p_dense8x8", "720p_dense8x8"])
     ap.add_argument("--params", default="code_defaults", choices=["code_defaults", "shipped_env"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample budget (0 = skip)")
@@ -164,6 +164,8 @@ def make_spec(workload, seed):
         return synth.spec_1080p(seed=seed, sub=1), (1920, 1080, {})
     if workload == "4k_dense8x8":
         return synth.spec_4k(seed=seed, sub=2), (3840, 2160, {})
+    if workload == "4k_dense16":
+        return synth.spec_4k(seed=seed, sub=1), (3840, 2160, {})
     if workload == "4k_fine_dense4":
         return synth.spec_4k_fine_dense(seed=seed), (3840, 2160, dict(block_size=4, block_shift=2))
     return synth.spec_4k_fine(seed=seed), (3840, 2160, dict(block_size=4, block_shift=2))

@@ -50,7 +50,7 @@ VARIANTS = [("fb32", dict(MTGPU_FORCE_FB="32")), ("fb2", dict(MTGPU_FORCE_FB="2"
             ("fb2/b512", dict(MTGPU_FORCE_FB="2", MTGPU_FORCE_BLOCK="512")),
             ("fb2/b1024", dict(MTGPU_FORCE_FB="2", MTGPU_FORCE_BLOCK="1024")),
             ("fb32/b1024", dict(MTGPU_FORCE_FB="32", MTGPU_FORCE_BLOCK="1024"))]
-FRAMES = {"1080p_dense8x8": 4096, "1080p_dense16": 16384, "4k_dense8x8": 1024, "4k_fine": 256, "4k_fine_dense4": 1024,
+FRAMES = {"1080p_dense8x8": 4096, "1080p_dense16": 16384, "4k_dense8x8": 1024, "4k_fine": 256, "4k_fine_dense4": 1024, "4k_dense16": 16384,
           "480p_dense16": 262144, "480p_dense8x8": 65536, "720p_dense16": 131072, "720p_dense8x8": 32768}
 
 
