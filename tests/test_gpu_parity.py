@@ -1112,6 +1112,70 @@ def test_plain_c_example(tmp_path):
     assert "motion frames 30, segments 1, do_cut 1" in out.stdout and "[0.500, 2.467]" in out.stdout
 
 
+def test_cpp_decoder_adapter_example(tmp_path):
+    """examples/decoder_adapter_example.cpp: a custom FrameSource (what a decoder adapter looks like) driving
+    run_scan_pipeline.  The scene is rendered again here, in Python, and pushed through the oracle-driven
+    transcription of the reference's worker loop: motion frames, segments and savings must agree bit for bit,
+    with 1 and with 4 workers."""
+    import os
+    import subprocess
+    import types
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.dirname(m.LIB_PATH)
+    exe = str(tmp_path / "decoder_adapter_example")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-I" + os.path.join(root, "include"),
+                           "-I" + os.path.join(pkg, "csrc", "host"),
+                           os.path.join(root, "examples", "decoder_adapter_example.cpp"), "-o", exe, "-L" + pkg,
+                           "-lmtgpu", "-lpthread", "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib"])
+    W, H, FPS, GOP, N, TB = 1280, 720, 25, 25, 1500, 12800
+    gw, gh = (W + 15) // 16, (H + 15) // 16
+
+    def object_at(f):
+        t = f / FPS
+        if 8.0 <= t < 14.0:
+            return 4 + int((t - 8.0) * 10.0), 20
+        if 40.0 <= t < 43.0:
+            return 60 - int((t - 40.0) * 12.0), 9
+        return None
+
+    ys, xs = np.mgrid[0:gh, 0:gw]
+    frames = []
+    for f in range(N):
+        if f % GOP == 0:
+            frames.append(None)
+            continue
+        mv = np.zeros(gw * gh, dtype=m.MV_DTYPE)
+        mv["dst_x"], mv["dst_y"] = (xs * 16 + 8).ravel(), (ys * 16 + 8).ravel()
+        dx = np.zeros((gh, gw), dtype=np.int64)
+        dy = np.zeros((gh, gw), dtype=np.int64)
+        o = object_at(f)
+        if o:
+            dx[o[1]:o[1] + 3, o[0]:o[0] + 4], dy[o[1]:o[1] + 3, o[0]:o[0] + 4] = 6, -1
+        if f & 1:
+            dx[30, 70], dy[30, 70] = -9, 4
+        mv["src_x"], mv["src_y"] = mv["dst_x"] - dx.ravel(), mv["dst_y"] - dy.ravel()
+        frames.append(mv)
+    ticks = [f * (TB // FPS) for f in range(N)]
+    spec = types.SimpleNamespace(fps=float(FPS), tb_den=TB)
+    p = ob.params_from_config(W, H, vectors_needed=1)
+    mp = m.MergeParams(duration=N / FPS)                       # code defaults: gap 5 s, padding 0.5 s, 5 %
+    pooled, (want_seg, want_res) = _reference_worker_loop(spec, frames, ticks, N / FPS, p, 30.0, 0.0, mp)
+    assert len(pooled) == 216 and len(want_seg) == 2 and want_res["do_cut"] == 1        # 144 + 72 frames, two passes
+    env = {k: v for k, v in os.environ.items() if k not in ("VECTORS_NEEDED", "CHUNK_DURATION_SEC", "TARGET_FPS",
+                                                            "MAX_GAP_SEC", "PADDING_SEC", "MIN_SAVINGS_PCT",
+                                                            "MV_THRESHOLD_SQ", "CLUSTERS_NEEDED", "VERTICAL_MASK")}
+    for threads in ("1", "4"):
+        out = subprocess.run([exe, threads], check=True, capture_output=True, text=True, env=env).stdout.splitlines()
+        head = dict(zip(out[0].split()[0::2], out[0].split()[1::2]))
+        assert (head["chunks"], head["motion_frames"]) == ("2", "216") and int(head["frames_scanned"]) == N
+        res = dict(zip(out[1].split()[0::2], out[1].split()[1::2]))
+        assert int(res["do_cut"]) == 1
+        assert float(res["time_removed"]).hex() == float(want_res["time_removed"]).hex()
+        assert float(res["saved_pct"]).hex() == float(want_res["saved_pct"]).hex()
+        segs = [[float(x).hex() for x in ln.split()[1:]] for ln in out[2:]]
+        assert segs == [[float(a).hex(), float(b).hex()] for a, b in want_seg.tolist()]
+
+
 def test_plain_c_pipe_example(tmp_path):
     """examples/pipe_example.c: the decoder-thread usage of the pinned pipe (acquire / add_frame /
     submit / collect / release with back-pressure) from plain C, end to end on the GPU."""
