@@ -654,6 +654,26 @@ struct ScanJob {
   PipelineResult result;
 };
 
+// The text the untouched cut executor builds from a job's segments and feeds to `ffmpeg -f concat`
+// (ffmpeg_executor.cpp:38-50, same lines in pipeline.cpp:464-470): per segment with end > start
+//   file '<absolute input path>' / inpoint <start, 2 decimals> / outpoint <end, 2 decimals>.
+// This is where the doubles of the merge are rounded for the first time ({:.2f} of fmt == "%.2f": correctly
+// rounded decimal of the exact binary value); a consumer that wants to diff against the reference's cut list
+// without running ffmpeg formats it here.  Convenience only: the hand-off to the executor is ScanJob::segments.
+inline std::string concat_list(const std::vector<mt_segment> &segments, const std::string &abs_input_path) {
+  std::string out;
+  char line[64];
+  for (const mt_segment &s : segments) {
+    if (s.end <= s.start) continue;                                      // :45-46
+    out += "file '" + abs_input_path + "'\n";
+    std::snprintf(line, sizeof line, "inpoint %.2f\n", s.start);
+    out += line;
+    std::snprintf(line, sizeof line, "outpoint %.2f\n", s.end);
+    out += line;
+  }
+  return out;
+}
+
 class JobQueue {   // producer/consumer queue of finished scans, as ffmpeg_queue.cpp:10-34
   std::queue<ScanJob> q_;
   std::mutex mu_;

@@ -155,6 +155,20 @@ def make_chunks(duration: float, chunk_sec: Optional[float] = None) -> List[Tupl
     return out
 
 
+def concat_list(segments, abs_input_path: str) -> str:
+    """The text the reference's cut executor feeds to `ffmpeg -f concat` for a job's segments
+    (src/ffmpeg_executor.cpp:38-50): per segment with end > start three lines — file '<path>', inpoint and
+    outpoint with two decimals (fmt's {:.2f} == "%.2f").  Convenience for diffing against the reference's cut
+    list; the hand-off itself is the segment doubles."""
+    out = []
+    for s in segments:
+        a, b = float(s[0]), float(s[1])
+        if b <= a:
+            continue
+        out.append("file '%s'\ninpoint %.2f\noutpoint %.2f\n" % (abs_input_path, a, b))
+    return "".join(out)
+
+
 def _ptr(a: Optional[np.ndarray]):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 

@@ -214,8 +214,18 @@ static int cmd_devices(int streams, int threads, int n_dev) {
   return 0;
 }
 
+// concat <path> < "start end" lines: the cut list the executor would write (ffmpeg_executor.cpp:38-50)
+static int cmd_concat(const char *path) {
+  std::vector<mt_segment> segs;
+  double a, b;
+  while (std::cin >> a >> b) segs.push_back(mt_segment{a, b});
+  std::fputs(h::concat_list(segs, path).c_str(), stdout);
+  return 0;
+}
+
 int main(int argc, char **argv) {
   const std::string cmd = argc > 1 ? argv[1] : "";
+  if (cmd == "concat" && argc == 3) return cmd_concat(argv[2]);
   if (cmd == "config") return cmd_config();
   if (cmd == "memo") return cmd_memo();
   if (cmd == "layout") return cmd_layout();

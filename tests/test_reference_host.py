@@ -19,6 +19,7 @@ import os
 import random
 import subprocess
 
+import numpy as np
 import pytest
 
 import mvtrim_amd as m
@@ -299,3 +300,22 @@ def test_stream_to_gpu_assignment(host_probe):
     assert rows == [[0, 0, 0, 0]] * 3
     rows = [[int(x) for x in ln.split(":")[1].split()] for ln in run(host_probe, ["devices", "2", "3", "4"])]
     assert rows == [[0, 1, 2], [3, 0, 1]]
+
+
+def test_concat_list_text(host_probe):
+    """The text stage right behind the path (src/ffmpeg_executor.cpp:38-50, hand-derived: the reference's executor
+    cannot run here — no ffmpeg): three lines per segment, `end <= start` skipped, two decimals of the exact binary
+    value ("%.2f" == fmt {:.2f}: 0.125 -> 0.12, 0.375 -> 0.38, 2.675 -> 2.67 because 2.675 is 2.67499999...).
+    C++ host layer and Python mirror must print the same bytes."""
+    segs = [(0.0, 1.5), (7.540000000000001, 14.46), (3.0, 3.0), (5.0, 4.0), (0.125, 0.375), (2.675, 1e3 + 0.005),
+            (59.533333333333339, 61.466666666666669)]
+    want = ("file '/v/a b.mp4'\ninpoint 0.00\noutpoint 1.50\n"
+            "file '/v/a b.mp4'\ninpoint 7.54\noutpoint 14.46\n"
+            "file '/v/a b.mp4'\ninpoint 0.12\noutpoint 0.38\n"
+            "file '/v/a b.mp4'\ninpoint 2.67\noutpoint 1000.00\n"
+            "file '/v/a b.mp4'\ninpoint 59.53\noutpoint 61.47\n")
+    assert m.concat_list(segs, "/v/a b.mp4") == want
+    stdin = "".join(f"{a!r} {b!r}\n" for a, b in segs)
+    out = subprocess.run([host_probe, "concat", "/v/a b.mp4"], input=stdin, capture_output=True, text=True, check=True).stdout
+    assert out == want
+    assert m.concat_list([], "/x") == "" and m.concat_list(np.zeros((0, 2)), "/x") == ""
