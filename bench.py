@@ -349,6 +349,8 @@ def host_fed_batch64(exe, n=12, reps=600, extra_env=None, configs=((64, 1), (16,
                 "frames_per_s_sum_of_streams": (float(np.mean([j["frames_scanned"] / max(j["scan_work_us"] * 1e-6, 1e-9)
                                                                for j in jobs])) * streams) if jobs else None,
                 "wall_ms": s["wall_us"] / 1e3, "wall_ms_until_last_video": s.get("scan_wall_us", 0) / 1e3,
+                # CPU time of the whole process over the run (getrusage) / wall: how many CPUs it kept busy
+                "cpus_busy": {"user": s.get("cpu_user_us", 0) / max(s["wall_us"], 1), "sys": s.get("cpu_sys_us", 0) / max(s["wall_us"], 1)},
                 "setup_ms": {"mtgpu_create_total": s["held"].get("ctx_create_us", 0) / 1e3,
                              "mtgpu_pipe_create_per_worker": s["held"].get("pipe_create_us", 0) / 1e3 / max(workers, 1)},
                 "worker_time_share": {"init": s["init_us"] / (workers * wall * 1e6),

@@ -133,7 +133,8 @@ enum {
   MT_ERR_CAPACITY = 2,  /* output buffer too small (n_out still reports need)  */
   MT_ERR_DEVICE = 3,    /* HIP runtime error (see *_last_error())              */
   MT_ERR_NOMEM = 4,
-  MT_ERR_BUSY = 5       /* every staging buffer of a pipe is in flight: collect first */
+  MT_ERR_BUSY = 5,      /* every staging buffer of a pipe is in flight: collect first */
+  MT_ERR_UNSUPPORTED = 6 /* the host CPU lacks the instruction set that was asked for      */
 };
 
 #ifdef __cplusplus

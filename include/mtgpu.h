@@ -146,6 +146,20 @@ int mtgpu_scan_frames_device_compact(mtgpu_ctx *ctx, const void *d_rec8, uint64_
 /* Host helper (data movement only, no result is computed): copy bytes 6..13 of each of
  * n_records 40-byte AVMotionVector records at `mv_bytes` into 8-byte compact records at `out8`. */
 int mtgpu_pack_records(const void *mv_bytes, uint64_t n_records, void *out8);
+/* The copy-out loop behind mtgpu_pack_records and mtgpu_batch_add_frame is chosen once per process from
+ * what the host CPU supports (AVX-512BW: five 64-byte loads -> one full 64-byte line per 8 records; AVX2;
+ * scalar), with non-temporal full-line stores into the staging the GPU reads next (csrc/pack_simd.cpp;
+ * MTGPU_PACK=scalar|avx2|avx512 and MTGPU_PACK_NT=0|1 override).  mtgpu_pack_selected() reports the
+ * choice; mtgpu_pack_records_with runs one given loop (tests, microbenchmarks): byte-identical output,
+ * MT_ERR_UNSUPPORTED if this CPU cannot run it. */
+#define MT_PACK_SCALAR 1
+#define MT_PACK_AVX2 2
+#define MT_PACK_AVX512 3
+#define MT_PACK_IMPL_MASK 15
+#define MT_PACK_NT 16        /* OR-ed in: non-temporal stores (vector loops, 8-byte aligned destination) */
+#define MT_PACK_PREFETCH_LINES(n) (((n) & 255) << 8)   /* OR-ed in: software-prefetch the source n 64-byte lines ahead */
+int mtgpu_pack_records_with(int impl_flags, const void *mv_bytes, uint64_t n_records, void *out8);
+int mtgpu_pack_selected(void);
 
 /* Same for HOST pointers: validates frame_off, copies the batch to the device,
  * scans, copies the flags back, synchronous.  This is the call an adapter makes

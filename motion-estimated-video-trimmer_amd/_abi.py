@@ -15,7 +15,9 @@ LIB_PATH = os.path.join(PKG_DIR, "libmtgpu.so")
 
 LAYOUT_COMPACT8, LAYOUT_AOS40, LAYOUT_ZERO_COPY = 0, 1, 2
 COMPACT_DTYPE = np.dtype([("src_x", "<i2"), ("src_y", "<i2"), ("dst_x", "<i2"), ("dst_y", "<i2")])
-MT_OK, MT_ERR_INVALID, MT_ERR_CAPACITY, MT_ERR_DEVICE, MT_ERR_NOMEM, MT_ERR_BUSY = 0, 1, 2, 3, 4, 5
+MT_OK, MT_ERR_INVALID, MT_ERR_CAPACITY, MT_ERR_DEVICE, MT_ERR_NOMEM, MT_ERR_BUSY, MT_ERR_UNSUPPORTED = 0, 1, 2, 3, 4, 5, 6
+# copy-out loops of mtgpu_pack_records_with (include/mtgpu.h)
+PACK_SCALAR, PACK_AVX2, PACK_AVX512, PACK_IMPL_MASK, PACK_NT = 1, 2, 3, 15, 16
 
 # AVMotionVector-compatible record (include/mt_types.h: mt_mv; 40 bytes).
 MV_DTYPE = np.dtype(
@@ -93,6 +95,8 @@ ABI = {
     "mtgpu_scan_frames_device_compact": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p,
                                                    C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     "mtgpu_pack_records": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p]),
+    "mtgpu_pack_records_with": (C.c_int, [C.c_int, C.c_void_p, C.c_uint64, C.c_void_p]),
+    "mtgpu_pack_selected": (C.c_int, []),
     "mtgpu_scan_frames": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_uint32, C.c_void_p]),
     "mtgpu_merge_segments": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(MergeParamsC),

@@ -16,7 +16,5 @@ int ctx_device(const mtgpu_ctx *c);
 // rec_bytes: MT_MV_BYTES (AVMotionVector records) or MT_COMPACT_BYTES (packed src/dst fields).
 int ctx_launch_scan(mtgpu_ctx *c, const void *d_mv, uint64_t n_records, const uint64_t *d_off,
                     const uint8_t *d_sd, uint32_t n_frames, uint8_t *d_flags, hipStream_t st, int rec_bytes);
-// bytes 6..13 of each 40-byte record -> 8-byte compact records (host data movement).
-void pack_records(const unsigned char *mv, uint64_t n, unsigned char *out);
 
 }  // namespace mtgpu

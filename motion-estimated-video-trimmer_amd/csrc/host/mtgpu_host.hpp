@@ -36,6 +36,7 @@
 
 #include <fcntl.h>
 #include <sys/mman.h>
+#include <sys/resource.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -709,6 +710,8 @@ struct BatchSummary {   // what a whole process_batch run did and what it held (
                                                            // only each stream's first video pays set-up, before this window)
   long long window_begin_abs_us = 0, window_end_abs_us = 0;
   long init_us = 0, decode_us = 0, analyze_us = 0, copy_us = 0, submit_us = 0, wait_us = 0;   // summed over all workers
+  long cpu_user_us = 0, cpu_sys_us = 0;                    // CPU time the whole process spent during the run (getrusage):
+                                                           // (user + sys) / wall = CPUs kept busy, against the box's quota
   Resources held;                                          // summed over the S x T backends alive at the end
 };
 
@@ -727,6 +730,8 @@ int process_batch(const std::vector<std::string> &files, const std::string &outp
   sum.threads_per_stream = threads_per_stream;
   sum.videos = files.size();
   const auto wall0 = std::chrono::high_resolution_clock::now();
+  struct rusage ru0{};
+  (void)getrusage(RUSAGE_SELF, &ru0);
   std::vector<std::thread> streams;
   for (int s = 0; s < parallel_streams; ++s) {
     streams.emplace_back([&, s] {
@@ -804,6 +809,13 @@ int process_batch(const std::vector<std::string> &files, const std::string &outp
   sum.scan_window_us = (long)(sum.window_end_abs_us - sum.window_begin_abs_us);
   sum.wall_us = (long)std::chrono::duration_cast<std::chrono::microseconds>(
                     std::chrono::high_resolution_clock::now() - wall0).count();
+  {
+    struct rusage ru1{};
+    (void)getrusage(RUSAGE_SELF, &ru1);
+    auto us = [](const timeval &a, const timeval &b) { return (long)(b.tv_sec - a.tv_sec) * 1000000L + (long)(b.tv_usec - a.tv_usec); };
+    sum.cpu_user_us = us(ru0.ru_utime, ru1.ru_utime);
+    sum.cpu_sys_us = us(ru0.ru_stime, ru1.ru_stime);
+  }
   if (summary) *summary = sum;
   return failed.load();
 }

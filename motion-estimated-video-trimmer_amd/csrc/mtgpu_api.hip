@@ -14,6 +14,7 @@
 
 #include "../../include/mtgpu.h"
 #include "api_internal.h"
+#include "pack_simd.h"
 #include "merge_kernels.h"
 #include "scan_kernels.h"
 
@@ -383,15 +384,7 @@ int launch_scan_on(mtgpu_ctx *c, const void *d_mv, uint64_t n_records, const uin
 }  // namespace
 
 namespace mtgpu {
-// Data movement only (no result is computed on the host): bytes 6..13 of every 40-byte
-// AVMotionVector -> one packed 8-byte record.
-void pack_records(const unsigned char *mv, uint64_t n, unsigned char *out) {
-  for (uint64_t i = 0; i < n; ++i) {
-    uint64_t v;
-    std::memcpy(&v, mv + i * MT_MV_BYTES + 6, 8);
-    std::memcpy(out + i * MT_COMPACT_BYTES, &v, 8);
-  }
-}
+// (the host copy-out loop, pack_records, lives in pack_simd.cpp: a plain host TU with per-CPU dispatch)
 int ctx_device(const mtgpu_ctx *c) { return c->device; }
 int ctx_launch_scan(mtgpu_ctx *c, const void *d_mv, uint64_t n_records, const uint64_t *d_off,
                     const uint8_t *d_sd, uint32_t n_frames, uint8_t *d_flags, hipStream_t st, int rec_bytes) {
@@ -578,6 +571,22 @@ int mtgpu_pack_records(const void *mv_bytes, uint64_t n_records, void *out8) {
   mtgpu::pack_records(static_cast<const unsigned char *>(mv_bytes), n_records, static_cast<unsigned char *>(out8));
   return MT_OK;
 }
+
+int mtgpu_pack_records_with(int impl_flags, const void *mv_bytes, uint64_t n_records, void *out8) {
+  const int impl = impl_flags & MT_PACK_IMPL_MASK;
+  if ((impl_flags & ~(MT_PACK_IMPL_MASK | MT_PACK_NT | MT_PACK_PREFETCH_LINES(255))) != 0 || impl < MT_PACK_SCALAR ||
+      impl > MT_PACK_AVX512)
+    return fail(MT_ERR_INVALID, "impl_flags must be MT_PACK_SCALAR, MT_PACK_AVX2 or MT_PACK_AVX512, optionally "
+                "| MT_PACK_NT | MT_PACK_PREFETCH_LINES(0..255)");
+  if (n_records > 0 && (!mv_bytes || !out8)) return fail(MT_ERR_INVALID, "NULL argument");
+  const uint64_t prefetch = 64ull * (uint64_t)((impl_flags >> 8) & 255);
+  if (mtgpu::pack_records_with(impl_flags & (MT_PACK_IMPL_MASK | MT_PACK_NT), static_cast<const unsigned char *>(mv_bytes),
+                               n_records, static_cast<unsigned char *>(out8), prefetch) != 0)
+    return fail(MT_ERR_UNSUPPORTED, "this CPU cannot run the requested copy-out loop");
+  return MT_OK;
+}
+
+int mtgpu_pack_selected(void) { return mtgpu::pack_selected(); }
 
 int mtgpu_debug_read_ceiling(mtgpu_ctx *c, const void *d_buf, uint64_t bytes, void *stream) {
   if (!c) return fail(MT_ERR_INVALID, "ctx is NULL");

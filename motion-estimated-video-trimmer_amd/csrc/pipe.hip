@@ -33,6 +33,7 @@
 #include <vector>
 
 #include "api_internal.h"
+#include "pack_simd.h"
 
 struct mtgpu_batch {
   // pinned host staging.  Offsets, has_sd bytes and records share ONE block
@@ -76,6 +77,7 @@ struct mtgpu_pipe {
   size_t slab_bytes = 0, d_slab_bytes = 0;
   int rec_bytes = MT_COMPACT_BYTES;
   bool zero_copy = false;
+  bool blocking_events = false;  // MTGPU_EVENT_BLOCKING=1: collect sleeps on the batch's event instead of polling it
   long inject_submit_fail = 0;   // MTGPU_INJECT_SUBMIT_FAIL=k (tests): the k-th submit fails after its copies were queued
   long inject_collect_fail = 0;  // MTGPU_INJECT_COLLECT_FAIL=k (tests): the k-th collect's event wait "fails";
                                  // negative: its stream drain "fails" as well (the batch is poisoned)
@@ -196,7 +198,8 @@ int alloc_batch(mtgpu_batch **out, mtgpu_pipe *p, size_t off, unsigned char *sla
     PIPE_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
     // system-scope release at the event: the flag bytes a zero-copy scan wrote into pinned memory
     // are visible to the host thread that waits on it
-    PIPE_TRY(hipEventCreateWithFlags(&b->done, hipEventDisableTiming | hipEventReleaseToSystem));
+    PIPE_TRY(hipEventCreateWithFlags(&b->done, hipEventDisableTiming | hipEventReleaseToSystem |
+                                                   (p->blocking_events ? hipEventBlockingSync : 0u)));
   }
   *out = b;
   return MT_OK;
@@ -238,6 +241,7 @@ int mtgpu_pipe_create_layout(mtgpu_ctx *ctx, uint64_t max_records_per_batch, uin
   p->ctx = ctx;
   p->rec_bytes = (layout & MT_LAYOUT_AOS40) ? MT_MV_BYTES : MT_COMPACT_BYTES;
   p->zero_copy = (layout & MT_LAYOUT_ZERO_COPY) != 0;
+  if (const char *v = std::getenv("MTGPU_EVENT_BLOCKING")) p->blocking_events = std::atol(v) != 0;
   if (const char *v = std::getenv("MTGPU_INJECT_SUBMIT_FAIL")) p->inject_submit_fail = std::atol(v);
   if (const char *v = std::getenv("MTGPU_INJECT_GROW_FAIL")) p->inject_grow_fail = std::atol(v) != 0;
   if (const char *v = std::getenv("MTGPU_INJECT_COLLECT_FAIL")) p->inject_collect_fail = std::atol(v);
