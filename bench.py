@@ -75,6 +75,10 @@ def parse(argv=None):
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --same-device rehearses the N>1 control flow on a 1-GPU box")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--rank-timeout", type=float, default=240.0,
+                    help="N > 1 only: a rank whose log and stderr stay silent this many seconds is taken to be hung — "
+                         "the launcher terminates every rank and exits 124 (per-rank logs are kept); inside a rank the "
+                         "same limit bounds the process-group collectives and arms a traceback dump + exit (0 = off)")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal: run the distributed code path (process group, async all_gather of segment lists, "
                          "barriers, max-over-ranks reduction, rank identity gather) even with ONE rank — executes the "
@@ -118,36 +122,95 @@ def rank_log_path(rank):
     return os.path.join(d if os.path.isdir(d) else ROOT, f"bench_rank{rank}.err")
 
 
-def launch_ranks(a, argv, environ=None, popen=subprocess.Popen):
+def rank_evidence(rank):
+    """(bytes, newest mtime) over the files a rank writes while it lives: its stage log and its stderr file."""
+    size, mtime = 0, 0.0
+    for path in (rank_log_path(rank), rank_log_path(rank) + ".stderr.log"):
+        try:
+            st = os.stat(path)
+        except OSError:
+            continue
+        size += st.st_size
+        mtime = max(mtime, st.st_mtime)
+    return size, mtime
+
+
+def launch_ranks(a, argv, environ=None, popen=subprocess.Popen, clock=time.monotonic, sleep=time.sleep,
+                 evidence=rank_evidence, report=None):
     """Start a.gpus fresh rank processes of this script (the parent never touches HIP, and no
     process that has is ever re-exec'ed), wait for all of them; rank 0's stdout (the JSON line)
-    is ours.  Returns the exit code: non-zero if any rank failed."""
+    is ours.  Returns the exit code: non-zero if any rank failed.
+
+    Watchdog (first contact with N > 1 ranks happens on the driver's box): every rank appends a line to
+    bench_rank{r}.err at each stage and its stderr goes to bench_rank{r}.err.stderr.log; a live rank whose
+    evidence has not grown for --rank-timeout seconds is hung (a collective that never completes, a rendezvous
+    that never forms): every rank is terminated (killed 5 s later if it ignores that), the verdict is written to
+    bench_launcher.err next to the rank logs, and the exit code is 124.  `clock`, `sleep`, `evidence` and
+    `popen` are injectable (tests/test_bench_contract.py)."""
     environ = dict(os.environ if environ is None else environ)
     envs = rank_environments(a.gpus, environ, free_port())
     cmd = [sys.executable, os.path.abspath(__file__)] + list(argv)
+    limit = float(getattr(a, "rank_timeout", 0) or 0)
+    if report is None:
+        def report(text):
+            sys.stderr.write(text + "\n")
+            try:
+                with open(os.path.join(os.path.dirname(rank_log_path(0)), "bench_launcher.err"), "a") as f:
+                    f.write(text + "\n")
+            except OSError:
+                pass
     # rank 0 keeps this process's stdout / stderr; the other ranks' stderr is kept in files (a rank that dies
-    # takes the run down: the reason must survive it)
+    # takes the run down: the reason must survive it, and the file's growth is a sign of life)
     procs = []
     for r, e in enumerate(envs):
+        for stale in (rank_log_path(r), rank_log_path(r) + ".stderr.log"):
+            try:
+                os.remove(stale)
+            except OSError:
+                pass
         if r == 0:
             procs.append(popen(cmd, env=e, stdout=None))
         else:
             with open(rank_log_path(r) + ".stderr.log", "wb") as errf:
                 procs.append(popen(cmd, env=e, stdout=subprocess.DEVNULL, stderr=errf))
     rc = 0
-    pending = list(procs)
+    pending = {r: p for r, p in enumerate(procs)}
+    seen = {r: (evidence(r), clock()) for r in pending}      # rank -> (last evidence, when it last changed)
+    killed_at = None
     while pending:
-        for p in list(pending):
+        now = clock()
+        for r, p in list(pending.items()):
             code = p.poll()
             if code is None:
+                ev = evidence(r)
+                if ev != seen[r][0]:
+                    seen[r] = (ev, now)
                 continue
-            pending.remove(p)
+            del pending[r]
             if code != 0 and rc == 0:
                 rc = code
-                for q in pending:                 # a rank died: the others would wait forever in a collective
+                report(f"bench launcher: rank {r} exited with code {code}; terminating the other ranks "
+                       f"(they would wait forever in a collective)")
+                for q in pending.values():
                     q.terminate()
+                killed_at = now
+        if pending and limit > 0 and killed_at is None:
+            silent = {r: now - seen[r][1] for r in pending}
+            hung = [r for r, dt in silent.items() if dt > limit]
+            if hung:
+                report(f"bench launcher: rank(s) {hung} silent for more than {limit:.0f} s (no new line in "
+                       f"bench_rank*.err, no stderr) — taken to be hung; terminating all {len(pending)} live ranks. "
+                       f"Last stage per rank is the last line of its bench_rank{{r}}.err")
+                for q in pending.values():
+                    q.terminate()
+                killed_at = now
+                rc = rc or 124
+        if pending and killed_at is not None and now - killed_at > 5.0:
+            for q in pending.values():             # ignored SIGTERM (stuck in the driver): SIGKILL
+                q.kill()
+            killed_at = now + 3600.0               # once
         if pending:
-            time.sleep(0.05)
+            sleep(0.05)
     return rc
 
 
@@ -351,8 +414,15 @@ def host_fed_batch64(exe, n=12, reps=600, extra_env=None, configs=((64, 1), (16,
                 "wall_ms": s["wall_us"] / 1e3, "wall_ms_until_last_video": s.get("scan_wall_us", 0) / 1e3,
                 # CPU time of the whole process over the run (getrusage) / wall: how many CPUs it kept busy
                 "cpus_busy": {"user": s.get("cpu_user_us", 0) / max(s["wall_us"], 1), "sys": s.get("cpu_sys_us", 0) / max(s["wall_us"], 1)},
+                # CPU time the worker threads got / the wall time they spent copying + submitting (waiting sleeps):
+                # well below 1 = workers were runnable but not running (more runnable threads than the CPU budget)
+                "worker_cpu_over_copy_submit_wall": s.get("worker_cpu_us", 0) / max(s["copy_us"] + s["submit_us"], 1),
+                "cpu_gate": {"tokens": s.get("gate_tokens", 0), "wait_share_of_worker_time": s.get("gate_wait_us", 0) / (workers * wall * 1e6)},
                 "setup_ms": {"mtgpu_create_total": s["held"].get("ctx_create_us", 0) / 1e3,
-                             "mtgpu_pipe_create_per_worker": s["held"].get("pipe_create_us", 0) / 1e3 / max(workers, 1)},
+                             "mtgpu_pipe_create_per_worker": s["held"].get("pipe_create_us", 0) / 1e3 / max(workers, 1),
+                             # page-locking incl. the batches pinned later, on first use (summed over the run / per worker)
+                             "page_locking_per_worker": s["held"].get("pin_us", 0) / 1e3 / max(workers, 1),
+                             "batches_pinned": s["held"].get("pinned_batches", 0)},
                 "worker_time_share": {"init": s["init_us"] / (workers * wall * 1e6),
                                       "reading_frames": s["decode_us"] / busy,
                                       "copy_out_to_pinned": s["copy_us"] / busy,
@@ -502,13 +572,29 @@ def _run_rank(a):
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     ident = device_identity(torch, dev, rank, local)
+    def stage(name, **kw):
+        """One line per stage in this rank's log: evidence for the driver, and the launcher's sign of life."""
+        if multi:
+            with open(rank_log_path(rank), "a") as f:
+                f.write(json.dumps({"stage": name, "t": round(time.time(), 3), **kw}) + "\n")
+
     if multi:
         with open(rank_log_path(rank), "w") as f:
             f.write(json.dumps({"stage": "start", **ident}) + "\n")
+        limit = float(a.rank_timeout or 0)
+        if limit > 0 and world > 1:
+            # a rank that is still here after 2 x the limit dumps every thread's stack into its log and exits
+            # (under torchrun there is no launcher of ours to notice a hang; the driver's kill would leave nothing)
+            import faulthandler
+            _fh = open(rank_log_path(rank) + ".hang.log", "w")
+            faulthandler.dump_traceback_later(2 * limit, exit=True, file=_fh)
+        import datetime
+        pg_kw = {"timeout": datetime.timedelta(seconds=limit)} if limit > 0 else {}
         if a.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, **pg_kw)
         else:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", **pg_kw)
+        stage("process_group_ready", backend=a.backend, world=world)
 
     # ---------------- synthetic input: `distinct` generated frames, tiled to `frames`
     arena = None
@@ -595,10 +681,12 @@ def _run_rank(a):
                     pending[k] = None
         merge_stream.synchronize()
 
+    stage("workload_resident", frames=a.frames)
     for _ in range(a.warmup):
         step()
     finish()
     torch.cuda.synchronize()
+    stage("warm")
     if multi:
         dist.barrier()
     torch.cuda.synchronize()
@@ -705,8 +793,12 @@ def _run_rank(a):
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     os.close(json_fd)
     if multi:
+        stage("line_printed" if rank == 0 else "waiting_for_rank_0")
         dist.barrier()
         dist.destroy_process_group()
+        stage("done")
+        import faulthandler
+        faulthandler.cancel_dump_traceback_later()
     scanner.close()
     del out
 

@@ -121,7 +121,16 @@ int mtgpu_debug_read_ceiling(mtgpu_ctx *ctx, const void *d_buf, uint64_t bytes, 
  * check_frame() over a device-resident batch — replaces the per-frame call at
  * src/motion_scanner.cpp:376 (body :217-295).
  *   d_mv         packed mt_mv records, n_records of them (device)
- *   d_frame_off  n_frames+1 record offsets (device); entries are clamped to n_records
+ *   d_frame_off  n_frames+1 record offsets (device), NON-DECREASING: frames are disjoint record ranges
+ *                (entries beyond n_records are clamped to it).  PRECONDITION, not checked by default — the
+ *                offsets live in device memory and the call is asynchronous.  With a decreasing entry two
+ *                frames overlap: a single-tile plan merely scans the shared records for both, but a banded
+ *                plan (mtgpu_get_plan: bands > 1) keeps frame f's vote queue at the frame's own offset, one
+ *                slot per record, so overlapping frames race on it and their flags are undefined.
+ *                MTGPU_CHECK_OFFSETS=1 in the environment of mtgpu_create makes both device entry points
+ *                verify the offsets on the device first (one small kernel + one stream synchronisation per
+ *                call) and return MT_ERR_INVALID, naming the first offending frame, before anything is scanned.
+ *                (mtgpu_scan_frames validates its HOST offsets always; the pipe builds its own.)
  *   d_has_sd     optional (device, may be NULL): has_sd[f]==0 <=> the frame had no
  *                AV_FRAME_DATA_MOTION_VECTORS side data (-> false, :219-221).
  *                NULL: a frame has side data iff it owns >= 1 record.
@@ -227,8 +236,11 @@ int mtgpu_merge_streams_device(mtgpu_ctx *ctx, const uint8_t *d_flags, const dou
  * (back-pressure: acquire fails with MT_ERR_BUSY until a batch is collected and released).
  * One pipe per decoder thread — the reference's one-MotionScanner-per-worker model
  * (src/pipeline.cpp:186-197); pipes of one context may be used concurrently, so N worker threads need
- * N pipes but only ONE context per device.  A pipe's staging is one pinned allocation (plus one device
- * allocation without MT_LAYOUT_ZERO_COPY) carved into its n_buffers batches.
+ * N pipes but only ONE context per device.  Each batch's staging is one pinned block (plus a device mirror
+ * without MT_LAYOUT_ZERO_COPY), page-locked when the batch is first used: creating a pipe pins one batch, the
+ * others follow on their first mtgpu_pipe_acquire (a few ms each), so S x T workers that start together are
+ * not queued behind S x T x n_buffers page-locking calls, and a worker that never has more than one batch in
+ * flight never pins the rest.
  */
 typedef struct mtgpu_pipe mtgpu_pipe;
 typedef struct mtgpu_batch mtgpu_batch;
@@ -248,7 +260,8 @@ int mtgpu_pipe_create_layout(mtgpu_ctx *ctx, uint64_t max_records_per_batch, uin
 void mtgpu_pipe_destroy(mtgpu_pipe *pipe);
 
 /* A free staging batch to fill, or MT_ERR_BUSY if all are in flight / held (MT_ERR_DEVICE if every batch
- * of the pipe was retired after failed collects: destroy the pipe). */
+ * of the pipe was retired after failed collects: destroy the pipe).  Pins the batch's staging on its first
+ * use; if that fails (MT_ERR_DEVICE / MT_ERR_NOMEM) the batch stays free and the pipe stays usable. */
 int mtgpu_pipe_acquire(mtgpu_pipe *pipe, mtgpu_batch **out);
 
 /* Append one decoded frame: copies n_bytes / 40 records (trailing bytes ignored, :226).
@@ -280,11 +293,16 @@ int mtgpu_pipe_release(mtgpu_pipe *pipe, mtgpu_batch *batch);
 /* What a pipe costs: every worker thread of the reference's N x S model (src/pipeline.cpp:186-197,
  * src/batch_processor.cpp:152-157) owns one pipe, so 64 streams x T workers multiply these. */
 typedef struct mtgpu_pipe_stats {
-  uint64_t pinned_bytes;   /* page-locked host memory: staging blocks + pts / tag / flag arrays    */
+  uint64_t pinned_bytes;   /* page-locked host memory SO FAR: staging blocks + pts / tag / flag arrays */
   uint64_t device_bytes;   /* device mirrors of the staging (0 with MT_LAYOUT_ZERO_COPY)           */
   uint64_t submits;        /* batches submitted so far                                             */
   uint32_t n_buffers;      /* staging batches = HIP streams = HIP events owned by the pipe         */
   int32_t layout;          /* MT_LAYOUT_* flags                                                    */
+  uint64_t pin_us;         /* time spent page-locking staging (creation, first uses, growth)       */
+  uint32_t pinned_batches; /* batches whose staging is pinned (the first at creation, the others   *
+                            * when mtgpu_pipe_acquire first hands them out; MTGPU_PIPE_EAGER=1:    *
+                            * all at creation)                                                     */
+  uint32_t _pad;
 } mtgpu_pipe_stats;
 int mtgpu_pipe_get_stats(mtgpu_pipe *pipe, mtgpu_pipe_stats *out);
 

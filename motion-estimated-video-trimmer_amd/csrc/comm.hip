@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <dlfcn.h>
+#include <rccl/rccl.h>
 
 #include <mutex>
 #include <new>
@@ -16,18 +17,18 @@ namespace {
 using mtgpu::fail;
 using mtgpu::hip_fail;
 
-// Minimal RCCL surface (rccl.h): opaque comm, 128-byte id, result codes (0 = success).
-typedef struct ncclComm *ncclComm_t;
-typedef struct { char internal[MTGPU_UNIQUE_ID_BYTES]; } ncclUniqueId;
-enum { ncclUint8 = 1 };   // ncclDataType_t: ncclInt8 = 0, ncclUint8 = 1
+// RCCL's own types (ncclUniqueId, ncclComm_t, ncclDataType_t, ncclResult_t) come from its header; only the
+// LIBRARY is optional (dlopen), so nothing of <rccl/rccl.h> is called directly — every entry point goes through
+// a pointer typed with decltype of the header's declaration: a signature that drifts breaks the build, not a run.
+static_assert(sizeof(ncclUniqueId) == MTGPU_UNIQUE_ID_BYTES, "include/mtgpu.h: MTGPU_UNIQUE_ID_BYTES must be sizeof(ncclUniqueId)");
 
 struct Rccl {
   void *h = nullptr;
-  int (*GetUniqueId)(ncclUniqueId *) = nullptr;
-  int (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
-  int (*CommDestroy)(ncclComm_t) = nullptr;
-  int (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
-  const char *(*GetErrorString)(int) = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
 };
 
 Rccl g_rccl;
@@ -50,7 +51,7 @@ bool load_rccl() {
   return g_rccl.h != nullptr;
 }
 
-int rccl_fail(int rc, const char *what) {
+int rccl_fail(ncclResult_t rc, const char *what) {
   return fail(MT_ERR_DEVICE, "%s: %s", what, g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "RCCL error");
 }
 
@@ -67,8 +68,8 @@ int mtgpu_comm_unique_id(void *id_out) {
   if (!id_out) return fail(MT_ERR_INVALID, "id_out is NULL");
   if (!load_rccl()) return fail(MT_ERR_DEVICE, "librccl.so.1 not available: %s", dlerror() ? dlerror() : "");
   ncclUniqueId id;
-  int rc = g_rccl.GetUniqueId(&id);
-  if (rc != 0) return rccl_fail(rc, "ncclGetUniqueId");
+  ncclResult_t rc = g_rccl.GetUniqueId(&id);
+  if (rc != ncclSuccess) return rccl_fail(rc, "ncclGetUniqueId");
   __builtin_memcpy(id_out, id.internal, MTGPU_UNIQUE_ID_BYTES);
   return MT_OK;
 }
@@ -84,8 +85,8 @@ int mtgpu_comm_create(int rank, int n_ranks, const void *id, int device, mtgpu_c
   if (!c) return fail(MT_ERR_NOMEM, "out of host memory");
   ncclUniqueId uid;
   __builtin_memcpy(uid.internal, id, MTGPU_UNIQUE_ID_BYTES);
-  int rc = g_rccl.CommInitRank(&c->comm, n_ranks, uid, rank);
-  if (rc != 0) { delete c; return rccl_fail(rc, "ncclCommInitRank"); }
+  ncclResult_t rc = g_rccl.CommInitRank(&c->comm, n_ranks, uid, rank);
+  if (rc != ncclSuccess) { delete c; return rccl_fail(rc, "ncclCommInitRank"); }
   c->rank = rank; c->n_ranks = n_ranks; c->device = device;
   *out = c;
   return MT_OK;
@@ -105,9 +106,9 @@ int mtgpu_gather_segments(mtgpu_comm *c, const void *d_send, uint64_t bytes_per_
   if (!d_send || !d_recv) return fail(MT_ERR_INVALID, "NULL device pointer");
   hipError_t e = hipSetDevice(c->device);
   if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
-  int rc = g_rccl.AllGather(d_send, d_recv, (size_t)bytes_per_rank, ncclUint8, c->comm,
-                            static_cast<hipStream_t>(stream));
-  if (rc != 0) return rccl_fail(rc, "ncclAllGather");
+  ncclResult_t rc = g_rccl.AllGather(d_send, d_recv, (size_t)bytes_per_rank, ncclUint8, c->comm,
+                                     static_cast<hipStream_t>(stream));
+  if (rc != ncclSuccess) return rccl_fail(rc, "ncclAllGather");
   return MT_OK;
 }
 

@@ -8,8 +8,13 @@
 // AV_FRAME_DATA_MOTION_VECTORS bytes to GpuMotionScanner through the FrameSource interface.
 // Decoder settings follow what the reference configures (src/motion_scanner.cpp:148-172):
 // +export_mvs, no loop filter, no IDCT, B-frames skipped, fast + gray flags, one slice thread.
-// The reference decodes from an mmap'ed buffer through custom AVIO (memory_io.*, untouched and
-// out of scope); this source simply opens the path.
+// Difference from the reference, on purpose: the reference maps the whole file and reads it through custom
+// AVIO callbacks over that buffer (MemoryLoader::read / ::seek, src/memory_io.cpp:134-166, attached at
+// src/motion_scanner.cpp:71-97 with AVFMT_FLAG_CUSTOM_IO); memory_io is untouched and out of scope (SURVEY.md
+// §2 #8), so this source lets libavformat open the PATH itself.  Same packets, same decoder, same side data;
+// a maintainer who wants the mmap'ed input back passes their own AVIOContext in fmt_->pb before
+// avformat_open_input, exactly as the reference does.
+// SURVEY.md §8 row f4 stays "not built" until this file has been compiled and run against real FFmpeg.
 #pragma once
 
 #if !defined(MTGPU_WITH_LIBAV)
@@ -43,7 +48,6 @@ class LibavSource : public FrameSource {
   AVFrame *frame_ = nullptr;
   AVPacket *pkt_ = nullptr;
   int vs_ = -1;
-  bool draining_ = false;
 
   void fail(const char *what) { close(); throw std::runtime_error(what); }
   void close() {
@@ -66,6 +70,8 @@ class LibavSource : public FrameSource {
       if ((int)i != vs_) fmt_->streams[i]->discard = AVDISCARD_ALL;
     const AVCodecParameters *par = fmt_->streams[vs_]->codecpar;
     const AVCodec *codec = avcodec_find_decoder(par->codec_id);
+    if (!codec)      // the reference's by-name fallback for builds whose id table lacks the entry (src/motion_scanner.cpp:126-131)
+      codec = avcodec_find_decoder_by_name(par->codec_id == AV_CODEC_ID_HEVC ? "hevc" : "h264");
     if (!codec) fail("no decoder");
     dec_ = avcodec_alloc_context3(codec);
     if (!dec_ || avcodec_parameters_to_context(dec_, par) < 0) fail("decoder context");
@@ -103,7 +109,6 @@ class LibavSource : public FrameSource {
     const int64_t ts = static_cast<int64_t>(seconds / time_base());
     av_seek_frame(fmt_, vs_, ts, AVSEEK_FLAG_BACKWARD);
     avcodec_flush_buffers(dec_);
-    draining_ = false;
   }
 
   bool next(Frame &out) override {
@@ -117,8 +122,9 @@ class LibavSource : public FrameSource {
         out.mv_bytes = sd ? (size_t)sd->size : 0;
         return true;                            // bytes stay valid until the next call
       }
-      if (got != AVERROR(EAGAIN) || draining_) return false;
-      // the decoder wants input: feed the next video packet
+      // got < 0 — EAGAIN (the decoder wants input) or a decode error: either way the reference leaves its
+      // receive loop and reads the next packet (src/motion_scanner.cpp:347-351, 334); only the end of the
+      // file ends the range (the decoder is never drained there either)
       bool fed = false;
       while (!fed) {
         if (av_read_frame(fmt_, pkt_) < 0) {    // end of file: the reference stops here too

@@ -19,7 +19,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <charconv>
 #include <chrono>
+#include <ctime>
 #include <cmath>
 #include <condition_variable>
 #include <cstdint>
@@ -35,6 +37,7 @@
 #include <vector>
 
 #include <fcntl.h>
+#include <sched.h>
 #include <sys/mman.h>
 #include <sys/resource.h>
 #include <sys/stat.h>
@@ -94,6 +97,78 @@ struct Config {   // same variables, defaults and parse types as config.hpp:56-1
     (void)mv_threshold_sq(); (void)block_size(); (void)block_shift(); (void)vectors_needed(); (void)clusters_needed();
     (void)vertical_mask(); (void)max_gap_sec(); (void)padding_sec(); (void)chunk_duration_sec(); (void)target_fps();
     (void)min_savings_pct(); (void)staging_layout(); (void)batch_mib();
+  }
+};
+
+// ---------------------------------------------------------------- CPU budget
+// CPUs' worth of run time this process may use — the order of the reference's detect_cpu_limit()
+// (src/system.cpp:107-164): cgroup v2 cpu.max, cgroup v1 cfs quota, cpuset, hardware_concurrency.
+inline int cpu_limit() {
+  auto read_two = [](const char *path, long &a, long &b) {
+    FILE *f = std::fopen(path, "r");
+    if (!f) return false;
+    char q[64] = "", p[64] = "";
+    const int n = std::fscanf(f, "%63s %63s", q, p);
+    std::fclose(f);
+    if (n < 1 || !std::strcmp(q, "max")) return false;
+    a = std::atol(q);
+    b = n >= 2 ? std::atol(p) : 0;
+    return true;
+  };
+  long quota = 0, period = 0;
+  if (read_two("/sys/fs/cgroup/cpu.max", quota, period) && quota > 0 && period > 0)
+    return (int)((quota + period - 1) / period);
+  long dummy = 0;
+  if (read_two("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", quota, dummy) && read_two("/sys/fs/cgroup/cpu/cpu.cfs_period_us", period, dummy) &&
+      quota > 0 && period > 0)
+    return (int)((quota + period - 1) / period);
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > 0) return CPU_COUNT(&set);
+  const unsigned hc = std::thread::hardware_concurrency();
+  return hc ? (int)hc : 1;
+}
+
+// At most `tokens` workers of the process FILL a staging batch (decode + copy-out) at any time; waiting for the GPU
+// holds no token.  The reference never runs more stream threads than CPUs (calculate_parallel_streams,
+// src/system.cpp:186-197: min(configured, detect_cpu_limit())); with GPUs in place of CPU sets the number of open
+// streams is no longer tied to CPUs (BASELINE config 4: 64 streams), but runnable threads still are: 64 runnable
+// workers under a 16-CPU cgroup quota were each scheduled ~16 % of the time while "copying" (the quota is handed
+// to CPUs in slices; round 4, profiles/r04_host_feed_*.json), i.e. a copy-out that streams 37 GB/s per thread
+// when it runs delivered 2.7 GB/s per worker.  The gate keeps the runnable set at the CPU budget.
+// MTGPU_CPU_TOKENS: 0 = no gate, N = that many tokens, unset = cpu_limit().
+class CpuGate {
+  std::mutex mu_;
+  std::condition_variable cv_;
+  int free_ = 0, tokens_ = 0;
+  std::atomic<uint64_t> waits_{0}, wait_us_{0};
+ public:
+  explicit CpuGate(int tokens) : free_(tokens), tokens_(tokens) {}
+  static CpuGate &instance() {
+    static CpuGate g([] {
+      const char *e = std::getenv("MTGPU_CPU_TOKENS");
+      return e ? std::max(0, std::atoi(e)) : cpu_limit();
+    }());
+    return g;
+  }
+  int tokens() const { return tokens_; }
+  uint64_t waits() const { return waits_.load(); }
+  uint64_t wait_us() const { return wait_us_.load(); }
+  void acquire() {
+    if (tokens_ <= 0) return;
+    std::unique_lock<std::mutex> l(mu_);
+    if (free_ == 0) {
+      const auto t0 = std::chrono::steady_clock::now();
+      cv_.wait(l, [&] { return free_ > 0; });
+      ++waits_;
+      wait_us_ += (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+    }
+    --free_;
+  }
+  void release() {
+    if (tokens_ <= 0) return;
+    { std::lock_guard<std::mutex> l(mu_); ++free_; }
+    cv_.notify_one();
   }
 };
 
@@ -237,8 +312,11 @@ struct Resources {
   uint64_t contexts = 0, pipes = 0, hip_streams = 0, hip_events = 0, mem_pools = 0;
   uint64_t pinned_bytes = 0, device_bytes = 0, pool_reserved_high = 0, submits = 0;
   uint64_t ctx_create_us = 0, pipe_create_us = 0;        // set-up time spent in mtgpu_create / mtgpu_pipe_create_layout
+  uint64_t pipe_rebuilds = 0;                            // pipes thrown away and re-created after a device-side failure
+  uint64_t pin_us = 0, pinned_batches = 0;               // page-locking time of the pipes (creation + lazy first uses) / batches pinned
   void add(const Resources &o) {
-    ctx_create_us += o.ctx_create_us; pipe_create_us += o.pipe_create_us;
+    ctx_create_us += o.ctx_create_us; pipe_create_us += o.pipe_create_us; pipe_rebuilds += o.pipe_rebuilds;
+    pin_us += o.pin_us; pinned_batches += o.pinned_batches;
     contexts += o.contexts; pipes += o.pipes; hip_streams += o.hip_streams; hip_events += o.hip_events;
     mem_pools += o.mem_pools; pinned_bytes += o.pinned_bytes; device_bytes += o.device_bytes;
     pool_reserved_high += o.pool_reserved_high; submits += o.submits;
@@ -289,18 +367,25 @@ class GpuBackend {
   std::shared_ptr<SharedContext> shared_;
   mtgpu_pipe *pipe_ = nullptr;
   int width_ = -1, height_ = -1, device_ = -1;
-  uint64_t pipe_us_ = 0;
+  uint64_t pipe_us_ = 0, rebuilds_ = 0;
+  bool dirty_ = false;
  public:
   GpuBackend() = default;
   ~GpuBackend() { reset(); }
   GpuBackend(const GpuBackend &) = delete;
   GpuBackend &operator=(const GpuBackend &) = delete;
   void reset() {
-    if (pipe_) mtgpu_pipe_destroy(pipe_);        // the pipe first: it launches on the context
+    if (pipe_) mtgpu_pipe_destroy(pipe_);        // the pipe first: it launches on the context (destroy drains it)
     pipe_ = nullptr;
     shared_.reset();
     width_ = height_ = device_ = -1;
+    dirty_ = false;
   }
+  // A scanner that leaves this backend's pipe in an unknown state — a submit or collect failed, a batch may still
+  // be in flight or retired (state 4) — marks it: the next video must not inherit that pipe (it would fail every
+  // acquire, or collect the previous video's batch and pool ITS timestamps).  ensure() then rebuilds it.
+  void mark_dirty() { dirty_ = true; }
+  bool dirty() const { return dirty_; }
   mtgpu_ctx *ctx() { return shared_ ? shared_->get() : nullptr; }
   mtgpu_pipe *pipe() { return pipe_; }
   const void *context_identity() const { return shared_.get(); }
@@ -308,10 +393,12 @@ class GpuBackend {
   Resources resources() {
     Resources r;
     r.pipe_create_us = pipe_us_;
+    r.pipe_rebuilds = rebuilds_;
     mtgpu_pipe_stats ps;
     if (pipe_ && mtgpu_pipe_get_stats(pipe_, &ps) == MT_OK) {
       r.pipes = 1; r.hip_streams += ps.n_buffers; r.hip_events += ps.n_buffers;
       r.pinned_bytes += ps.pinned_bytes; r.device_bytes += ps.device_bytes; r.submits = ps.submits;
+      r.pin_us = ps.pin_us; r.pinned_batches = ps.pinned_batches;
     }
     return r;
   }
@@ -334,7 +421,8 @@ class GpuBackend {
   // a backend already set up for this frame size and device is reused as it is.
   bool ensure(int width, int height, int device, uint64_t batch_records, uint32_t batch_frames, int n_buffers,
               std::string &err) {
-    if (shared_ && pipe_ && width == width_ && height == height_ && device == device_) return true;
+    if (shared_ && pipe_ && !dirty_ && width == width_ && height == height_ && device == device_) return true;
+    if (dirty_) ++rebuilds_;
     reset();
     mt_scan_params p;
     int rc = mtgpu_params_from_config(&p, width, height, Config::mv_threshold_sq(), Config::block_size(),
@@ -367,7 +455,13 @@ class GpuMotionScanner {   // public shape of MotionScanner (motion_scanner.hpp:
     return (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::high_resolution_clock::now() - t0).count();
   }
 
-  bool ok(int rc) { if (rc != MT_OK) { err_ = mtgpu_last_error(); return false; } return true; }
+  bool device_error_ = false;                         // a submit / collect / release failed: the pipe's state is unknown
+  bool ok(int rc) {
+    if (rc == MT_OK) return true;
+    err_ = mtgpu_last_error();
+    if (rc != MT_ERR_CAPACITY && rc != MT_ERR_BUSY && rc != MT_ERR_INVALID) device_error_ = true;
+    return false;
+  }
 
   bool collect_one(std::vector<double> &ts) {
     mtgpu_batch *b = nullptr;
@@ -387,6 +481,11 @@ class GpuMotionScanner {   // public shape of MotionScanner (motion_scanner.hpp:
     --inflight_;
     return ok(mtgpu_pipe_release(pipe_, b));
   }
+  // the CPU token (CpuGate) is held exactly while a batch is being filled: from its acquire to its submit / release
+  bool token_ = false;
+  void take_token() { if (!token_) { CpuGate::instance().acquire(); token_ = true; } }
+  void drop_token() { if (token_) { CpuGate::instance().release(); token_ = false; } }
+  void release_current() { if (cur_) { mtgpu_pipe_release(pipe_, cur_); cur_ = nullptr; } drop_token(); }
   bool submit() {
     if (!cur_) return true;
     const auto s0 = std::chrono::high_resolution_clock::now();
@@ -394,6 +493,7 @@ class GpuMotionScanner {   // public shape of MotionScanner (motion_scanner.hpp:
     submit_us_ += since(s0);
     if (!sent) return false;
     cur_ = nullptr;
+    drop_token();
     ++inflight_;
     return true;
   }
@@ -401,8 +501,9 @@ class GpuMotionScanner {   // public shape of MotionScanner (motion_scanner.hpp:
     for (;;) {
       if (!cur_) {
         int rc = mtgpu_pipe_acquire(pipe_, &cur_);
-        if (rc == MT_ERR_BUSY) { if (!collect_one(ts)) return false; continue; }   // back-pressure
+        if (rc == MT_ERR_BUSY) { if (!collect_one(ts)) return false; continue; }   // back-pressure (no token held)
         if (!ok(rc)) return false;
+        take_token();
       }
       const auto c0 = std::chrono::high_resolution_clock::now();
       int rc = mtgpu_batch_add_frame(cur_, f.mv, f.mv_bytes, f.has_side_data ? 1 : 0, pts, 0);
@@ -417,10 +518,13 @@ class GpuMotionScanner {   // public shape of MotionScanner (motion_scanner.hpp:
   GpuMotionScanner(FrameSource &src, int device, GpuBackend *shared = nullptr)
       : src_(src), device_(device), be_(shared ? shared : &own_) {}
   ~GpuMotionScanner() {      // leave a shared pipe idle: nothing in flight, nothing half-filled
-    if (!pipe_) return;
+    if (!pipe_) { drop_token(); return; }
     std::vector<double> sink;
     while (inflight_ > 0 && collect_one(sink)) {}
-    if (cur_) { mtgpu_pipe_release(pipe_, cur_); cur_ = nullptr; }
+    release_current();
+    // anything that went wrong on the device side, or a batch that could not be collected: the pipe is not
+    // handed to the next video as it is (GpuBackend::ensure rebuilds a dirty backend; destroying a pipe drains it)
+    if (device_error_ || inflight_ > 0) be_->mark_dirty();
   }
   GpuMotionScanner(const GpuMotionScanner &) = delete;
   GpuMotionScanner &operator=(const GpuMotionScanner &) = delete;
@@ -433,6 +537,11 @@ class GpuMotionScanner {   // public shape of MotionScanner (motion_scanner.hpp:
   long submit_us() const { return submit_us_; }
   long wait_us() const { return wait_us_; }
   uint64_t frames_fed() const { return frames_fed_; }
+  // The scan context of this worker's device.  It is SHARED by every worker of the process that scans the same
+  // frame size on that device (SharedContext): treat it as read-only — query it (mtgpu_get_plan / _get_params /
+  // _get_stats) and pass it to the merge, but do not call per-context mutators (mtgpu_set_slices) or the
+  // host-pointer scan entry points on it from a worker: they take the context's lock and its single stream and
+  // would serialise or re-plan all S x T workers.  (run_scan_pipeline's own merge call is one short call per video.)
   mtgpu_ctx *context() { return be_->ctx(); }
 
   // batch_records == 0: sized from the source and the staging layout — MTGPU_BATCH_MB MiB of
@@ -493,7 +602,7 @@ class GpuMotionScanner {   // public shape of MotionScanner (motion_scanner.hpp:
       std::vector<double> sink;
       const std::string first = err_;
       while (inflight_ > 0 && collect_one(sink)) {}
-      if (cur_) { mtgpu_pipe_release(pipe_, cur_); cur_ = nullptr; }
+      release_current();
       err_ = first;
     } else {
       while (inflight_ > 0) if (!collect_one(ts)) break;
@@ -518,6 +627,8 @@ struct PipelineResult {
                                                           // needs them to find the window in which ANY video was scanned)
   long copy_us = 0, submit_us = 0, wait_us = 0;      // parts of analyze_us (summed over workers): copy-out into pinned
                                                      // staging, submit calls, waiting for the GPU
+  long worker_cpu_us = 0;                            // CPU time the worker threads actually got (CLOCK_THREAD_CPUTIME_ID, summed):
+                                                     // far below their wall time = they were runnable but not running
   std::string error;
 };
 
@@ -554,6 +665,7 @@ int run_scan_pipeline(MakeSource make_source, int num_threads, PipelineResult &o
     tasks.push({t, std::min(t + chunk, duration), chunk_id++});
   std::atomic<long> seek_us{0}, decode_us{0}, analyze_us{0}, init_us{0}, copy_us{0}, submit_us{0}, wait_us{0};
   std::atomic<uint64_t> frames_scanned{0};
+  std::atomic<long> worker_cpu_us{0};
   const auto wall0 = std::chrono::high_resolution_clock::now();
   std::mutex err_mu;
   std::vector<std::thread> workers;
@@ -608,6 +720,8 @@ int run_scan_pipeline(MakeSource make_source, int num_threads, PipelineResult &o
         seek_us += s; decode_us += d; analyze_us += a;
         copy_us += scanners[i]->copy_us(); submit_us += scanners[i]->submit_us(); wait_us += scanners[i]->wait_us();
         frames_scanned += scanners[i]->frames_fed();
+        struct timespec tc{};
+        if (clock_gettime(CLOCK_THREAD_CPUTIME_ID, &tc) == 0) worker_cpu_us += (long)tc.tv_sec * 1000000L + tc.tv_nsec / 1000;
       } catch (const std::exception &e) {
         fail_with(std::string("worker ") + std::to_string(i) + ": " + e.what());
       } catch (...) {
@@ -622,6 +736,7 @@ int run_scan_pipeline(MakeSource make_source, int num_threads, PipelineResult &o
   out.seek_us = seek_us; out.decode_us = decode_us; out.analyze_us = analyze_us; out.init_us = init_us;
   out.copy_us = copy_us; out.submit_us = submit_us; out.wait_us = wait_us;
   out.frames_scanned = frames_scanned;
+  out.worker_cpu_us = worker_cpu_us;
   {
     const auto wall1 = std::chrono::high_resolution_clock::now();
     out.scan_wall_us = (long)std::chrono::duration_cast<std::chrono::microseconds>(wall1 - wall0).count();
@@ -662,15 +777,19 @@ struct ScanJob {
 // rounded decimal of the exact binary value); a consumer that wants to diff against the reference's cut list
 // without running ffmpeg formats it here.  Convenience only: the hand-off to the executor is ScanJob::segments.
 inline std::string concat_list(const std::vector<mt_segment> &segments, const std::string &abs_input_path) {
+  // fmt's {:.2f} prints every digit of the exact binary value and ignores the C locale; std::to_chars(fixed, 2)
+  // does the same (snprintf("%.2f") would follow LC_NUMERIC's decimal comma and needs a buffer sized for 1e308)
+  auto fixed2 = [](double v) {
+    char buf[400];                                          // DBL_MAX has 309 integer digits
+    const std::to_chars_result r = std::to_chars(buf, buf + sizeof buf, v, std::chars_format::fixed, 2);
+    return r.ec == std::errc() ? std::string(buf, r.ptr) : std::string("nan");
+  };
   std::string out;
-  char line[64];
   for (const mt_segment &s : segments) {
     if (s.end <= s.start) continue;                                      // :45-46
     out += "file '" + abs_input_path + "'\n";
-    std::snprintf(line, sizeof line, "inpoint %.2f\n", s.start);
-    out += line;
-    std::snprintf(line, sizeof line, "outpoint %.2f\n", s.end);
-    out += line;
+    out += "inpoint " + fixed2(s.start) + "\n";
+    out += "outpoint " + fixed2(s.end) + "\n";
   }
   return out;
 }
@@ -710,6 +829,8 @@ struct BatchSummary {   // what a whole process_batch run did and what it held (
                                                            // only each stream's first video pays set-up, before this window)
   long long window_begin_abs_us = 0, window_end_abs_us = 0;
   long init_us = 0, decode_us = 0, analyze_us = 0, copy_us = 0, submit_us = 0, wait_us = 0;   // summed over all workers
+  long worker_cpu_us = 0;                                  // CPU time the worker threads got (thread clocks, summed)
+  long gate_wait_us = 0; int gate_tokens = 0;              // CpuGate: time workers waited for a CPU token / tokens
   long cpu_user_us = 0, cpu_sys_us = 0;                    // CPU time the whole process spent during the run (getrusage):
                                                            // (user + sys) / wall = CPUs kept busy, against the box's quota
   Resources held;                                          // summed over the S x T backends alive at the end
@@ -732,6 +853,7 @@ int process_batch(const std::vector<std::string> &files, const std::string &outp
   const auto wall0 = std::chrono::high_resolution_clock::now();
   struct rusage ru0{};
   (void)getrusage(RUSAGE_SELF, &ru0);
+  const uint64_t gate_wait0 = CpuGate::instance().wait_us();
   std::vector<std::thread> streams;
   for (int s = 0; s < parallel_streams; ++s) {
     streams.emplace_back([&, s] {
@@ -790,6 +912,7 @@ int process_batch(const std::vector<std::string> &files, const std::string &outp
           }
           sum.init_us += r.init_us; sum.decode_us += r.decode_us; sum.analyze_us += r.analyze_us;
           sum.copy_us += r.copy_us; sum.submit_us += r.submit_us; sum.wait_us += r.wait_us;
+          sum.worker_cpu_us += r.worker_cpu_us;
         }
         if (rc != 0) {
           ++failed;
@@ -815,6 +938,8 @@ int process_batch(const std::vector<std::string> &files, const std::string &outp
     auto us = [](const timeval &a, const timeval &b) { return (long)(b.tv_sec - a.tv_sec) * 1000000L + (long)(b.tv_usec - a.tv_usec); };
     sum.cpu_user_us = us(ru0.ru_utime, ru1.ru_utime);
     sum.cpu_sys_us = us(ru0.ru_stime, ru1.ru_stime);
+    sum.gate_wait_us = (long)(CpuGate::instance().wait_us() - gate_wait0);
+    sum.gate_tokens = CpuGate::instance().tokens();
   }
   if (summary) *summary = sum;
   return failed.load();

@@ -80,6 +80,7 @@ struct mtgpu_ctx {
   int item_chunk = 0;    // MTGPU_ITEM_CHUNK (tests): workgroups per kernel launch, 0 = 2^30
   int lds_max = 0;       // device limit of LDS per workgroup
   int group_request = 0; // MTGPU_GROUP: frames per workgroup, 0 = automatic
+  int check_offsets = 0; // MTGPU_CHECK_OFFSETS=1: the device entry points verify "frame_off non-decreasing" first (one sync per call)
   int min_lds_kb = 0;    // MTGPU_MIN_LDS_KB: launch with at least this much LDS (caps workgroups per CU), 0 = automatic
   hipMemPool_t pool = nullptr;   // private stream-ordered pool for launch scratch (freed blocks stay cached)
   uint64_t merge_large_min = 4096;   // timestamp lists at least this long take the multi-workgroup merge (MTGPU_MERGE_LARGE_MIN)
@@ -252,6 +253,7 @@ int make_plan(mtgpu_ctx *c, int lds_max, int cu_count) {
   k.prefetch = env_int("MTGPU_PREFETCH", 1) != 0 ? 1 : 0;      // experiments: 0 switches the next-frame prefetch off
   c->group_request = env_int("MTGPU_GROUP", 0);
   c->min_lds_kb = env_int("MTGPU_MIN_LDS_KB", 0);
+  c->check_offsets = env_int("MTGPU_CHECK_OFFSETS", 0) != 0;
   c->item_chunk = env_int("MTGPU_ITEM_CHUNK", 0);
   if (c->item_chunk < 0) c->item_chunk = 0;
   {
@@ -539,6 +541,31 @@ int mtgpu_get_plan(const mtgpu_ctx *c, mtgpu_plan *out) {
   return MT_OK;
 }
 
+namespace {
+// MTGPU_CHECK_OFFSETS=1: verify the CSR precondition of the device entry points on the device, BEFORE the scan is
+// queued — costs one small kernel and one stream synchronisation per call, which is why it is opt-in.
+int check_offsets_on(mtgpu_ctx *c, const uint64_t *d_off, uint32_t n_frames, hipStream_t st) {
+  void *d_bad = nullptr;
+  hipError_t e = scratch_alloc(c, &d_bad, sizeof(unsigned int), st);
+  if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(offset check)");
+  unsigned int first_bad = 0xffffffffu;
+  e = hipMemsetAsync(d_bad, 0xff, sizeof(unsigned int), st);
+  if (e == hipSuccess)
+    e = mtgpu::launch_check_offsets(reinterpret_cast<const unsigned long long *>(d_off), n_frames,
+                                    static_cast<unsigned int *>(d_bad), st);
+  if (e == hipSuccess) e = hipMemcpyAsync(&first_bad, d_bad, sizeof first_bad, hipMemcpyDeviceToHost, st);
+  const hipError_t e2 = hipStreamSynchronize(st);
+  (void)hipFreeAsync(d_bad, st);
+  if (e != hipSuccess) return hip_fail(e, "frame_off check");
+  if (e2 != hipSuccess) return hip_fail(e2, "hipStreamSynchronize(frame_off check)");
+  if (first_bad != 0xffffffffu)
+    return fail(MT_ERR_INVALID, "frame_off[%u] > frame_off[%u]: record offsets must be non-decreasing "
+                "(frames are disjoint record ranges; a banded plan keeps each frame's spill queue at its offset)",
+                first_bad, first_bad + 1u);
+  return MT_OK;
+}
+}  // namespace
+
 int mtgpu_scan_frames_device(mtgpu_ctx *c, const void *d_mv, uint64_t n_records,
                              const uint64_t *d_frame_off, const uint8_t *d_has_sd,
                              uint32_t n_frames, uint8_t *d_flags, void *stream) {
@@ -548,6 +575,10 @@ int mtgpu_scan_frames_device(mtgpu_ctx *c, const void *d_mv, uint64_t n_records,
   if (n_records > 0 && !d_mv) return fail(MT_ERR_INVALID, "mv is NULL with n_records > 0");
   if (((uintptr_t)d_mv & 3u) != 0) return fail(MT_ERR_INVALID, "mv must be 4-byte aligned");
   HIP_TRY(hipSetDevice(c->device));
+  if (c->check_offsets) {
+    const int rc = check_offsets_on(c, d_frame_off, n_frames, static_cast<hipStream_t>(stream));
+    if (rc != MT_OK) return rc;
+  }
   return launch_scan_on(c, d_mv, n_records, d_frame_off, d_has_sd, n_frames, d_flags,
                         static_cast<hipStream_t>(stream));
 }
@@ -561,6 +592,10 @@ int mtgpu_scan_frames_device_compact(mtgpu_ctx *c, const void *d_rec8, uint64_t 
   if (n_records > 0 && !d_rec8) return fail(MT_ERR_INVALID, "records is NULL with n_records > 0");
   if (((uintptr_t)d_rec8 & 7u) != 0) return fail(MT_ERR_INVALID, "compact records must be 8-byte aligned");
   HIP_TRY(hipSetDevice(c->device));
+  if (c->check_offsets) {
+    const int rc = check_offsets_on(c, d_frame_off, n_frames, static_cast<hipStream_t>(stream));
+    if (rc != MT_OK) return rc;
+  }
   return launch_scan_on(c, d_rec8, n_records, d_frame_off, d_has_sd, n_frames, d_flags,
                         static_cast<hipStream_t>(stream), MT_COMPACT_BYTES);
 }

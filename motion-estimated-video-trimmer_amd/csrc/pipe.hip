@@ -24,6 +24,8 @@
 // only mtgpu_pipe_destroy touches its memory.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -36,29 +38,32 @@
 #include "pack_simd.h"
 
 struct mtgpu_batch {
-  // pinned host staging.  Offsets, has_sd bytes and records share ONE block
-  // ([off (cap_frames+1) x 8 | sd cap_frames | pad to 64 | records]) mirrored by one device
-  // block, so a batch goes up with a single H2D copy: with many decoder threads submitting
-  // concurrently the runtime's per-call cost, not PCIe, is what a submit pays for.
-  unsigned char *h_stage = nullptr;
+  // pinned host staging: ONE block per batch,
+  //   [off (cap_frames+1) x 8 | sd cap_frames | pad to 64 | records | pad to 64 | pts | tags | flags]
+  // so a batch goes up with a single H2D copy of its head (without zero-copy): with many decoder threads
+  // submitting concurrently the runtime's per-call cost, not PCIe, is what a submit pays for.  The block is
+  // pinned on the batch's FIRST use (mtgpu_pipe_acquire), not at pipe creation: page-locking costs ~0.2 ms per
+  // MiB whatever the block size and is serialised across threads by the driver (profiles/r04_pin_probe.json:
+  // 16 MiB 3.6 ms, 3 GiB 691 ms, 64 threads x 48 MiB at once 622 ms), so a worker that pins only what it is
+  // about to fill starts three times sooner and the rest of the pinning overlaps the scan.
+  unsigned char *h_stage = nullptr;  // the block (nullptr: not pinned yet)
   unsigned char *h_mv = nullptr;     // = h_stage + hdr_bytes
   uint64_t *h_off = nullptr;         // = h_stage
   uint8_t *h_sd = nullptr;           // = h_stage + (cap_frames + 1) * 8
   double *h_pts = nullptr;
   uint64_t *h_tag = nullptr;
   uint8_t *h_flags = nullptr;
-  // device mirrors
-  unsigned char *d_stage = nullptr;
+  // what the kernel dereferences: the device view of the pinned block (zero-copy) or a device mirror
+  unsigned char *d_stage = nullptr;  // the mirror to free later (nullptr with zero-copy)
   unsigned char *d_mv = nullptr;
   uint64_t *d_off = nullptr;
   uint8_t *d_sd = nullptr;
   uint8_t *d_flags = nullptr;
   size_t hdr_bytes = 0;
-  size_t stage_bytes = 0;             // size of h_stage (and of d_stage when it exists)
-  size_t aux_bytes = 0;               // pts + tag + flag arrays (pinned; flags mirrored on the device without zero-copy)
-  bool own_stage = false;             // h_stage / d_stage are this batch's own blocks (grown for an oversize frame),
-                                      // not slices of the pipe's slabs
+  size_t stage_bytes = 0;             // [off | sd | records] part of the block
+  size_t block_bytes = 0;             // the whole block: stage + pts / tag / flag arrays
   uint64_t cap_records = 0, n_records = 0;
+  uint64_t want_records = 0;          // capacity the block gets when it is pinned
   uint32_t cap_frames = 0, n_frames = 0;
   int rec_bytes = MT_COMPACT_BYTES;   // bytes per staged record: 8 (compact) or 40 (AoS)
   bool zero_copy = false;             // the scan reads the pinned staging (and writes the flags) over PCIe itself
@@ -70,20 +75,18 @@ struct mtgpu_batch {
 
 struct mtgpu_pipe {
   mtgpu_ctx *ctx = nullptr;
-  // ONE pinned slab (and, without zero-copy, one device slab) holds the staging of every batch: a pipe is set
-  // up with two allocations instead of six per batch — with 64 x T worker threads creating their pipes at
-  // once the driver serialises those calls, and 768 of them took ~0.7 s per worker (profiles/r03_host_batch64.json)
-  unsigned char *h_slab = nullptr, *d_slab = nullptr;
-  size_t slab_bytes = 0, d_slab_bytes = 0;
   int rec_bytes = MT_COMPACT_BYTES;
   bool zero_copy = false;
   bool blocking_events = false;  // MTGPU_EVENT_BLOCKING=1: collect sleeps on the batch's event instead of polling it
+  bool eager_pin = false;        // MTGPU_PIPE_EAGER=1: pin every batch at creation (round 3 behaviour)
   long inject_submit_fail = 0;   // MTGPU_INJECT_SUBMIT_FAIL=k (tests): the k-th submit fails after its copies were queued
   long inject_collect_fail = 0;  // MTGPU_INJECT_COLLECT_FAIL=k (tests): the k-th collect's event wait "fails";
                                  // negative: its stream drain "fails" as well (the batch is poisoned)
+  bool inject_once = false;      // MTGPU_INJECT_ONCE=1 (tests): an injected collect failure fires once per PROCESS, not per pipe
   long collects = 0;
   long submits = 0;
   bool inject_grow_fail = false; // MTGPU_INJECT_GROW_FAIL=1 (tests): growing a batch for an oversize frame fails
+  uint64_t pin_us = 0;           // time spent page-locking staging blocks (creation + first uses + growth)
   std::vector<mtgpu_batch *> bufs;
   std::deque<mtgpu_batch *> inflight;
   std::mutex mu;
@@ -97,10 +100,8 @@ using mtgpu::hip_fail;
 void free_batch(mtgpu_batch *b) {
   if (!b) return;
   if (b->stream) (void)hipStreamSynchronize(b->stream);
-  if (b->own_stage) {
-    if (b->h_stage) (void)hipHostFree(b->h_stage);
-    if (b->d_stage) (void)hipFree(b->d_stage);
-  }
+  if (b->h_stage) (void)hipHostFree(b->h_stage);
+  if (b->d_stage) (void)hipFree(b->d_stage);
   if (b->done) (void)hipEventDestroy(b->done);
   if (b->stream) (void)hipStreamDestroy(b->stream);
   delete b;
@@ -118,55 +119,51 @@ size_t aux_bytes_for(uint32_t cap_frames) {          // [pts (nf+1) x 8 | tags (
   return (nf * (sizeof(double) + sizeof(uint64_t)) + nf + 63u) & ~(size_t)63u;
 }
 
-// Point a batch's staging at `h` (pinned) / `dv` (what the kernel dereferences: the device view of the pinned
-// block with zero-copy, device memory otherwise) / `d_own` (the device block to free later, or nullptr).
-void set_stage(mtgpu_batch *b, unsigned char *h, unsigned char *dv, unsigned char *d_own, size_t hdr, size_t bytes,
-               uint64_t records) {
-  const size_t nf = (size_t)b->cap_frames;
-  b->h_stage = h;
-  b->d_stage = d_own;
-  b->hdr_bytes = hdr;
-  b->stage_bytes = bytes;
-  b->h_off = reinterpret_cast<uint64_t *>(h);
-  b->h_sd = h + sizeof(uint64_t) * (nf + 1);
-  b->h_mv = h + hdr;
-  b->d_off = reinterpret_cast<uint64_t *>(dv);
-  b->d_sd = dv + sizeof(uint64_t) * (nf + 1);
-  b->d_mv = dv + hdr;
-  b->h_off[0] = 0;
-  b->cap_records = records;
-}
-
 #define PIPE_TRY(expr)                                               \
   do {                                                               \
     hipError_t _e = (expr);                                          \
     if (_e != hipSuccess) { rc = hip_fail(_e, #expr); goto bad; }    \
   } while (0)
 
-// Give a batch its OWN, larger staging block for `records` records (a frame larger than a whole batch); the
-// batch must be idle and empty.  The new blocks are allocated BEFORE the old ones are let go: when that fails
-// the batch keeps its previous staging and capacity, so it stays usable.  Its slice of the pipe's slab (if it
-// still used one) simply stays unused from then on.
-int alloc_records(mtgpu_batch *b, uint64_t records, bool inject_failure = false) {
+// Pin (or re-pin, larger) a batch's staging block for `records` records.  The batch must be idle and empty.
+// The new blocks are allocated BEFORE the old ones are let go: when that fails the batch keeps what it had
+// (possibly nothing) and stays usable.  The caller has made the pipe's device current.
+int pin_block(mtgpu_batch *b, uint64_t records, bool inject_failure = false) {
   int rc = MT_OK;
   unsigned char *h_new = nullptr, *d_new = nullptr, *dev_view = nullptr;
   size_t hdr = 0;
-  const size_t bytes = stage_bytes_for(b->cap_frames, records, b->rec_bytes, &hdr);
+  const size_t sbytes = stage_bytes_for(b->cap_frames, records, b->rec_bytes, &hdr);
+  const size_t bytes = sbytes + aux_bytes_for(b->cap_frames);
+  const size_t nf = (size_t)b->cap_frames + 1;
   PIPE_TRY(hipHostMalloc(reinterpret_cast<void **>(&h_new), bytes, hipHostMallocDefault));
   if (inject_failure) { rc = fail(MT_ERR_NOMEM, "injected allocation failure (MTGPU_INJECT_GROW_FAIL)"); goto bad; }
   if (b->zero_copy) {
-    // no device mirror: the kernel reads the pinned block through its device-visible address
+    // no device mirror: the kernel reads the pinned block through its device-visible address and writes the
+    // flag bytes straight into it
     PIPE_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&dev_view), h_new, 0));
   } else {
     PIPE_TRY(hipMalloc(reinterpret_cast<void **>(&d_new), bytes));
     dev_view = d_new;
   }
-  if (b->own_stage) {
-    if (b->h_stage) (void)hipHostFree(b->h_stage);
-    if (b->d_stage) (void)hipFree(b->d_stage);
-  }
-  b->own_stage = true;
-  set_stage(b, h_new, dev_view, d_new, hdr, bytes, records);
+  if (b->h_stage) (void)hipHostFree(b->h_stage);
+  if (b->d_stage) (void)hipFree(b->d_stage);
+  b->h_stage = h_new;
+  b->d_stage = d_new;
+  b->hdr_bytes = hdr;
+  b->stage_bytes = sbytes;
+  b->block_bytes = bytes;
+  b->h_off = reinterpret_cast<uint64_t *>(h_new);
+  b->h_sd = h_new + sizeof(uint64_t) * nf;
+  b->h_mv = h_new + hdr;
+  b->h_pts = reinterpret_cast<double *>(h_new + sbytes);
+  b->h_tag = reinterpret_cast<uint64_t *>(h_new + sbytes + nf * sizeof(double));
+  b->h_flags = h_new + sbytes + nf * (sizeof(double) + sizeof(uint64_t));
+  b->d_off = reinterpret_cast<uint64_t *>(dev_view);
+  b->d_sd = dev_view + sizeof(uint64_t) * nf;
+  b->d_mv = dev_view + hdr;
+  b->d_flags = dev_view + sbytes + nf * (sizeof(double) + sizeof(uint64_t));
+  b->h_off[0] = 0;
+  b->cap_records = records;
   return MT_OK;
 bad:
   if (h_new) (void)hipHostFree(h_new);
@@ -174,32 +171,31 @@ bad:
   return rc;
 }
 
-// Batch i of a pipe: staging and result arrays are slices of the pipe's slabs at `off` (64-byte aligned).
-int alloc_batch(mtgpu_batch **out, mtgpu_pipe *p, size_t off, unsigned char *slab_dev_view, uint64_t max_records,
-                uint32_t max_frames) {
+int pin_block_timed(mtgpu_pipe *p, mtgpu_batch *b, uint64_t records, bool inject_failure = false) {
+  const auto t0 = std::chrono::steady_clock::now();
+  const int rc = pin_block(b, records, inject_failure);
+  p->pin_us += (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+  return rc;
+}
+
+// Batch i of a pipe: its stream and event now, its staging when `pin_now` (else on first acquire).
+int alloc_batch(mtgpu_batch **out, mtgpu_pipe *p, uint64_t max_records, uint32_t max_frames, bool pin_now) {
   int rc = MT_OK;
   mtgpu_batch *b = new (std::nothrow) mtgpu_batch();
   if (!b) return fail(MT_ERR_NOMEM, "out of host memory");
   b->cap_frames = max_frames;
+  b->want_records = max_records;
   b->rec_bytes = p->rec_bytes;
   b->zero_copy = p->zero_copy;
-  {
-    size_t hdr = 0;
-    const size_t sbytes = stage_bytes_for(max_frames, max_records, p->rec_bytes, &hdr);
-    const size_t nf = (size_t)max_frames + 1;
-    set_stage(b, p->h_slab + off, slab_dev_view + off, nullptr, hdr, sbytes, max_records);
-    unsigned char *aux = p->h_slab + off + sbytes;
-    b->aux_bytes = aux_bytes_for(max_frames);
-    b->h_pts = reinterpret_cast<double *>(aux);
-    b->h_tag = reinterpret_cast<uint64_t *>(aux + nf * sizeof(double));
-    b->h_flags = aux + nf * (sizeof(double) + sizeof(uint64_t));
-    // zero-copy: the kernel writes the flag bytes straight into the pinned slab; otherwise into the device slab
-    b->d_flags = slab_dev_view + off + sbytes + nf * (sizeof(double) + sizeof(uint64_t));
-    PIPE_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
-    // system-scope release at the event: the flag bytes a zero-copy scan wrote into pinned memory
-    // are visible to the host thread that waits on it
-    PIPE_TRY(hipEventCreateWithFlags(&b->done, hipEventDisableTiming | hipEventReleaseToSystem |
-                                                   (p->blocking_events ? hipEventBlockingSync : 0u)));
+  b->owner = p;
+  PIPE_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+  // system-scope release at the event: the flag bytes a zero-copy scan wrote into pinned memory
+  // are visible to the host thread that waits on it
+  PIPE_TRY(hipEventCreateWithFlags(&b->done, hipEventDisableTiming | hipEventReleaseToSystem |
+                                                 (p->blocking_events ? hipEventBlockingSync : 0u)));
+  if (pin_now) {
+    rc = pin_block_timed(p, b, max_records);
+    if (rc != MT_OK) goto bad;
   }
   *out = b;
   return MT_OK;
@@ -242,37 +238,22 @@ int mtgpu_pipe_create_layout(mtgpu_ctx *ctx, uint64_t max_records_per_batch, uin
   p->rec_bytes = (layout & MT_LAYOUT_AOS40) ? MT_MV_BYTES : MT_COMPACT_BYTES;
   p->zero_copy = (layout & MT_LAYOUT_ZERO_COPY) != 0;
   if (const char *v = std::getenv("MTGPU_EVENT_BLOCKING")) p->blocking_events = std::atol(v) != 0;
+  if (const char *v = std::getenv("MTGPU_PIPE_EAGER")) p->eager_pin = std::atol(v) != 0;
   if (const char *v = std::getenv("MTGPU_INJECT_SUBMIT_FAIL")) p->inject_submit_fail = std::atol(v);
   if (const char *v = std::getenv("MTGPU_INJECT_GROW_FAIL")) p->inject_grow_fail = std::atol(v) != 0;
   if (const char *v = std::getenv("MTGPU_INJECT_COLLECT_FAIL")) p->inject_collect_fail = std::atol(v);
-  {
-    const size_t per = stage_bytes_for(max_frames_per_batch, max_records_per_batch, p->rec_bytes, nullptr) +
-                       aux_bytes_for(max_frames_per_batch);
-    p->slab_bytes = per * (size_t)n_buffers;
-    unsigned char *dev_view = nullptr;
-    e = hipHostMalloc(reinterpret_cast<void **>(&p->h_slab), p->slab_bytes, hipHostMallocDefault);
-    if (e != hipSuccess) { p->h_slab = nullptr; mtgpu_pipe_destroy(p); return hip_fail(e, "hipHostMalloc(pipe staging)"); }
-    if (p->zero_copy) {
-      e = hipHostGetDevicePointer(reinterpret_cast<void **>(&dev_view), p->h_slab, 0);
-      if (e != hipSuccess) { mtgpu_pipe_destroy(p); return hip_fail(e, "hipHostGetDevicePointer"); }
-    } else {
-      e = hipMalloc(reinterpret_cast<void **>(&p->d_slab), p->slab_bytes);
-      if (e != hipSuccess) { p->d_slab = nullptr; mtgpu_pipe_destroy(p); return hip_fail(e, "hipMalloc(pipe staging mirror)"); }
-      p->d_slab_bytes = p->slab_bytes;
-      dev_view = p->d_slab;
+  if (const char *v = std::getenv("MTGPU_INJECT_ONCE")) p->inject_once = std::atol(v) != 0;
+  for (int i = 0; i < n_buffers; ++i) {
+    mtgpu_batch *b = nullptr;
+    // the first batch is pinned here (the caller is about to fill it), the others when they are first acquired
+    int rc = alloc_batch(&b, p, max_records_per_batch, max_frames_per_batch, i == 0 || p->eager_pin);
+    if (rc != MT_OK) {
+      char keep[512];
+      std::snprintf(keep, sizeof keep, "%s", mtgpu_last_error());
+      mtgpu_pipe_destroy(p);
+      return fail(rc, "%s", keep);
     }
-    for (int i = 0; i < n_buffers; ++i) {
-      mtgpu_batch *b = nullptr;
-      int rc = alloc_batch(&b, p, per * (size_t)i, dev_view, max_records_per_batch, max_frames_per_batch);
-      if (rc != MT_OK) {
-        char keep[512];
-        std::snprintf(keep, sizeof keep, "%s", mtgpu_last_error());
-        mtgpu_pipe_destroy(p);
-        return fail(rc, "%s", keep);
-      }
-      b->owner = p;
-      p->bufs.push_back(b);
-    }
+    p->bufs.push_back(b);
   }
   *out = p;
   return MT_OK;
@@ -282,23 +263,32 @@ void mtgpu_pipe_destroy(mtgpu_pipe *p) {
   if (!p) return;
   (void)hipSetDevice(mtgpu::ctx_device(p->ctx));
   for (mtgpu_batch *b : p->bufs) free_batch(b);      // drains every batch's stream first
-  if (p->h_slab) (void)hipHostFree(p->h_slab);
-  if (p->d_slab) (void)hipFree(p->d_slab);
   delete p;
 }
 
 int mtgpu_pipe_acquire(mtgpu_pipe *p, mtgpu_batch **out) {
   if (!p || !out) return fail(MT_ERR_INVALID, "NULL argument");
   std::lock_guard<std::mutex> lock(p->mu);
-  for (mtgpu_batch *b : p->bufs)
-    if (b->state == 0) {
-      b->state = 1;
-      b->n_frames = 0;
-      b->n_records = 0;
-      b->h_off[0] = 0;
-      *out = b;
-      return MT_OK;
+  mtgpu_batch *pick = nullptr;
+  for (mtgpu_batch *b : p->bufs)                    // a free batch that is already pinned, else one that is not yet
+    if (b->state == 0 && (b->h_stage || !pick)) {
+      pick = b;
+      if (b->h_stage) break;
     }
+  if (pick) {
+    if (!pick->h_stage) {                           // first use: page-lock its staging now
+      hipError_t e = use_device(mtgpu::ctx_device(p->ctx));
+      if (e != hipSuccess) { *out = nullptr; return hip_fail(e, "hipSetDevice"); }
+      const int rc = pin_block_timed(p, pick, pick->want_records);
+      if (rc != MT_OK) { *out = nullptr; return rc; }   // the batch stays free and unpinned
+    }
+    pick->state = 1;
+    pick->n_frames = 0;
+    pick->n_records = 0;
+    pick->h_off[0] = 0;
+    *out = pick;
+    return MT_OK;
+  }
   *out = nullptr;
   size_t retired = 0;
   for (const mtgpu_batch *b : p->bufs) retired += b->state == 4;
@@ -319,7 +309,7 @@ int mtgpu_batch_add_frame(mtgpu_batch *b, const void *mv_bytes, uint64_t n_bytes
     // buffers can be replaced.
     hipError_t e = hipSetDevice(mtgpu::ctx_device(b->owner->ctx));
     if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
-    int rc = alloc_records(b, n + n / 4, b->owner->inject_grow_fail);
+    int rc = pin_block_timed(b->owner, b, n + n / 4, b->owner->inject_grow_fail);
     if (rc != MT_OK) return rc;          // the batch keeps its previous staging and stays usable
   }
   if (n) {
@@ -397,7 +387,9 @@ int mtgpu_pipe_collect(mtgpu_pipe *p, mtgpu_batch **out, const uint8_t **flags, 
   { std::lock_guard<std::mutex> lock(p->mu); nth = ++p->collects; }
   *out = b;                       // handed out even on failure, so that it can be released
   hipError_t e = hipEventSynchronize(b->done);
-  const bool inject = p->inject_collect_fail != 0 && nth == std::labs(p->inject_collect_fail);
+  static std::atomic<bool> injected_once{false};
+  bool inject = p->inject_collect_fail != 0 && nth == std::labs(p->inject_collect_fail);
+  if (inject && p->inject_once && injected_once.exchange(true)) inject = false;
   if (inject && e == hipSuccess) e = hipErrorUnknown;
   if (e != hipSuccess) {
     // The kernel of this batch may still be running: nobody may refill (or free) its pinned staging
@@ -423,13 +415,13 @@ int mtgpu_pipe_get_stats(mtgpu_pipe *p, mtgpu_pipe_stats *out) {
   if (!p || !out) return fail(MT_ERR_INVALID, "NULL argument");
   std::lock_guard<std::mutex> lock(p->mu);
   std::memset(out, 0, sizeof *out);
-  out->pinned_bytes = p->slab_bytes;
-  out->device_bytes = p->d_slab_bytes;
   for (const mtgpu_batch *b : p->bufs)
-    if (b->own_stage) {                              // grown for an oversize frame: its own blocks on top of the slabs
-      out->pinned_bytes += b->stage_bytes;
-      if (!b->zero_copy) out->device_bytes += b->stage_bytes;
+    if (b->h_stage) {                                  // pinned so far (the others pin on first use)
+      out->pinned_bytes += b->block_bytes;
+      if (!b->zero_copy) out->device_bytes += b->block_bytes;
+      out->pinned_batches += 1;
     }
+  out->pin_us = p->pin_us;
   out->submits = (uint64_t)p->submits;
   out->n_buffers = (uint32_t)p->bufs.size();
   out->layout = (p->rec_bytes == MT_MV_BYTES ? MT_LAYOUT_AOS40 : MT_LAYOUT_COMPACT8) | (p->zero_copy ? MT_LAYOUT_ZERO_COPY : 0);

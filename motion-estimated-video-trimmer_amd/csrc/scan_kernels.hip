@@ -294,6 +294,7 @@ __device__ __forceinline__ unsigned long long compact_head(const unsigned char *
 template <int UNROLL>
 struct NextStep {
   u32x4 d[UNROLL];
+  unsigned int frame;   // the frame these loads belong to (workgroup-uniform, like `have`)
   bool have;
 };
 
@@ -312,6 +313,9 @@ __device__ __forceinline__ void scan_item(
   PT_DECL;
   const unsigned int f = SPILL ? item : item / (unsigned int)k.slices;
   const int slice = SPILL ? 0 : (int)(item - f * (unsigned int)k.slices);
+  // A pre-issued step is consumed only by the frame it was loaded for: whatever early-out a frame takes
+  // between here and its streaming loop, a step that was not consumed can never leak its votes into a LATER frame.
+  if (ns.have && ns.frame != f) ns.have = false;
 
   unsigned long long r0 = frame_off[f], r1 = frame_off[f + 1];
   r1 = r1 < n_records ? r1 : n_records;
@@ -319,7 +323,8 @@ __device__ __forceinline__ void scan_item(
   const bool sd = has_sd ? (has_sd[f] != 0) : (r1 > r0);
   if (!sd) {                                   // :219-221 — no side data: false
     if (slice == 0 && tid == 0) flags[f] = 0;
-    return;                                    // (ns.have is false here: a step is only pre-issued for frames with side data)
+    ns.have = false;                           // (never set for such a frame today: a step is only pre-issued for frames with side data)
+    return;
   }
   const unsigned long long q0 = r0;            // the frame's spill queue: one slot per record
   if (!SPILL && k.slices > 1) {                // this workgroup's share of the frame's records
@@ -399,8 +404,8 @@ __device__ __forceinline__ void scan_item(
           if (tid == 0 && ((n - head) & 1ull) != 0ull)
             vote<FB, MODE, SPILL>(decode(load_compact<VAR>(base + (n - 1ull) * 8ull)), k, t0, t1, cnt, sq);
           unsigned long long p = tid;
-          if (ns.have) {                       // this frame's first step was issued during the previous frame's cluster test
-            ns.have = false;
+          if (ns.have) {                       // this frame's first step (ns.frame == f, checked on entry) was issued during
+            ns.have = false;                   // the previous frame's cluster test
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) {
               vote<FB, MODE, SPILL>(decode((u32x2){ns.d[u].x, ns.d[u].y}), k, t0, t1, cnt, sq);
@@ -508,6 +513,7 @@ __device__ __forceinline__ void scan_item(
             for (int u = 0; u < UNROLL; ++u)
               ns.d[u] = load_pair<VAR>(npb + ((unsigned long long)tid + (unsigned long long)u * BLOCK) * 16ull);
             ns.have = true;
+            ns.frame = f + 1u;
           }
         }
       }
@@ -699,6 +705,7 @@ __global__ __launch_bounds__(BLOCK) void scan_frames_kernel(
   const unsigned int first = item0 + blockIdx.x * (unsigned int)k.group;
   NextStep<UNROLL> ns;
   ns.have = false;
+  ns.frame = 0u;
   for (int g = 0; g < k.group; ++g) {
     const unsigned int item = first + (unsigned int)g;
     if (item >= n_items) break;
@@ -742,6 +749,26 @@ hipError_t launch_read_ceiling(const void *p, unsigned long long bytes, unsigned
   if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
   hipLaunchKernelGGL(read_ceiling_kernel, dim3((unsigned int)blocks), dim3(512), 0, stream,
                      static_cast<const u32x4 *>(p), n16, sink);
+  return hipGetLastError();
+}
+
+// Opt-in precondition check of the device entry points (MTGPU_CHECK_OFFSETS=1): frame_off must be
+// non-decreasing — frames are then disjoint record ranges.  A banded plan keeps frame f's spill queue at
+// spill_q + frame_off[f], one slot per record, so frames that overlap would race on it.  *first_bad ends up as
+// the smallest f with frame_off[f] > frame_off[f + 1] (0xffffffff: none).
+__global__ __launch_bounds__(256) void check_offsets_kernel(const unsigned long long *__restrict__ frame_off,
+                                                            unsigned int n_frames, unsigned int *first_bad) {
+  for (unsigned long long f = (unsigned long long)blockIdx.x * 256ull + threadIdx.x; f < n_frames;
+       f += (unsigned long long)gridDim.x * 256ull)
+    if (frame_off[f] > frame_off[f + 1]) atomicMin(first_bad, (unsigned int)f);
+}
+
+hipError_t launch_check_offsets(const unsigned long long *frame_off, unsigned int n_frames, unsigned int *first_bad,
+                                hipStream_t stream) {
+  if (n_frames == 0) return hipSuccess;
+  const unsigned int blocks = (n_frames + 255u) / 256u;
+  hipLaunchKernelGGL(check_offsets_kernel, dim3(blocks < 1024u ? blocks : 1024u), dim3(256), 0, stream, frame_off,
+                     n_frames, first_bad);
   return hipGetLastError();
 }
 

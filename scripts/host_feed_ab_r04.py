@@ -12,27 +12,46 @@ import bench  # noqa: E402
 
 exe = os.path.join(ROOT, "motion-estimated-video-trimmer_amd", "mtgpu_scan_file")
 SETTINGS = {
-    "scalar (round 3 loop)": {"MTGPU_PACK": "scalar"},
-    "auto (vector loop, NT stores)": {},
-    "vector loop, ordinary stores": {"MTGPU_PACK_NT": "0"},
-    "auto + prefetch 1 KiB": {"MTGPU_PACK_PREFETCH": "1024"},
-    "scalar + blocking events": {"MTGPU_PACK": "scalar", "MTGPU_EVENT_BLOCKING": "1"},
-    "auto + blocking events": {"MTGPU_EVENT_BLOCKING": "1"},
+    "scalar (round 3 loop), no gate": {"MTGPU_PACK": "scalar", "MTGPU_CPU_TOKENS": "0"},
+    "auto (vector loop, NT stores), no gate": {"MTGPU_CPU_TOKENS": "0"},
+    "vector loop, ordinary stores, no gate": {"MTGPU_PACK_NT": "0", "MTGPU_CPU_TOKENS": "0"},
+    "auto + prefetch 1 KiB, no gate": {"MTGPU_PACK_PREFETCH": "1024", "MTGPU_CPU_TOKENS": "0"},
+    "auto + blocking events, no gate": {"MTGPU_EVENT_BLOCKING": "1", "MTGPU_CPU_TOKENS": "0"},
+    "auto, gate = cpu limit": {},
+    "auto, gate 8": {"MTGPU_CPU_TOKENS": "8"},
+    "auto, gate 12": {"MTGPU_CPU_TOKENS": "12"},
+    "auto, gate 24": {"MTGPU_CPU_TOKENS": "24"},
+    "auto + prefetch 1 KiB, gate = cpu limit": {"MTGPU_PACK_PREFETCH": "1024"},
+    "scalar, gate = cpu limit": {"MTGPU_PACK": "scalar"},
+    "auto + blocking events, gate = cpu limit": {"MTGPU_EVENT_BLOCKING": "1"},
 }
 only = os.environ.get("ONLY")
 if only:
     SETTINGS = {k: v for k, v in SETTINGS.items() if any(o.strip() in k for o in only.split(","))}
 configs = tuple(tuple(int(x) for x in c.split("x")) for c in os.environ.get("CONFIGS", "64x1,16x4").split(","))
+def cpu_stat():
+    try:
+        return {k: int(v) for k, v in (ln.split() for ln in open("/sys/fs/cgroup/cpu.stat"))}
+    except Exception:
+        return {}
+
+
 out = {}
 for p in range(int(os.environ.get("PASSES", "2"))):
     for name, env in SETTINGS.items():
+        c0 = cpu_stat()
         r = bench.host_fed_batch64(exe, reps=int(os.environ.get("REPS", "400")), extra_env=env, configs=configs)
+        c1 = cpu_stat()
+        throttle = {k: c1.get(k, 0) - c0.get(k, 0) for k in ("nr_periods", "nr_throttled", "throttled_usec")}
         keep = {k: {kk: vv for kk, vv in v.items() if kk in ("frames_per_s_wall", "frames_per_s_steady", "wall_ms", "setup_ms",
-                                                             "worker_time_share", "cpus_busy", "error")}
+                                                             "worker_time_share", "cpus_busy", "error",
+                                                             "worker_cpu_over_copy_submit_wall", "cpu_gate")}
                 for k, v in r.items() if isinstance(v, dict)}
+        keep["cgroup_cpu_stat_delta_incl_file_generation"] = throttle
         out.setdefault(name, []).append(keep)
         print(p, name, {k: (round(v.get("frames_per_s_steady") or 0), round(v.get("frames_per_s_wall") or 0),
                             round(v.get("worker_time_share", {}).get("copy_out_to_pinned", 0), 2),
-                            {a: round(b, 1) for a, b in v.get("cpus_busy", {}).items()}) for k, v in keep.items()},
+                            {a: round(b, 1) for a, b in v.get("cpus_busy", {}).items()},
+                            round(v.get("worker_cpu_over_copy_submit_wall", 0), 2)) for k, v in keep.items() if "x" in k}, throttle,
               file=sys.stderr, flush=True)
 print(json.dumps(out, indent=1))

@@ -3,6 +3,7 @@
 // tests/test_reference_host.py can compare the two line by line (fixture: tests/golden/reference_host_vectors.json,
 // recorded from the reference itself).  Needs no GPU: nothing here creates a scan context.
 #include <cstddef>
+#include <clocale>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -223,8 +224,38 @@ static int cmd_concat(const char *path) {
   return 0;
 }
 
+// gate N T R: T threads pass R times through a CpuGate of N tokens; prints the highest number of threads ever
+// inside at once, the passes made and whether anybody had to wait; `cpulimit` prints cpu_limit()
+static int cmd_gate(int tokens, int threads, int rounds) {
+  h::CpuGate gate(tokens);
+  std::atomic<int> inside{0}, peak{0}, passes{0};
+  std::vector<std::thread> th;
+  for (int t = 0; t < threads; ++t)
+    th.emplace_back([&] {
+      for (int r = 0; r < rounds; ++r) {
+        gate.acquire();
+        const int now = ++inside;
+        int p = peak.load();
+        while (now > p && !peak.compare_exchange_weak(p, now)) {}
+        std::this_thread::sleep_for(std::chrono::microseconds(200));
+        --inside;
+        ++passes;
+        gate.release();
+      }
+    });
+  for (auto &x : th) x.join();
+  std::printf("peak %d passes %d waited %d tokens %d\n", peak.load(), passes.load(), gate.waits() > 0 ? 1 : 0, gate.tokens());
+  return 0;
+}
+
 int main(int argc, char **argv) {
   const std::string cmd = argc > 1 ? argv[1] : "";
+  if (cmd == "gate" && argc == 5) return cmd_gate(std::atoi(argv[2]), std::atoi(argv[3]), std::atoi(argv[4]));
+  if (cmd == "cpulimit") { std::printf("%d\n", h::cpu_limit()); return 0; }
+  if (cmd == "concat" && argc == 4 && std::string(argv[3]) == "--setlocale") {
+    std::setlocale(LC_ALL, "");          // adopt LC_ALL from the environment, as a host application might
+    return cmd_concat(argv[2]);
+  }
   if (cmd == "concat" && argc == 3) return cmd_concat(argv[2]);
   if (cmd == "config") return cmd_config();
   if (cmd == "memo") return cmd_memo();

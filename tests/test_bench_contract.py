@@ -119,3 +119,84 @@ def test_bench_helpers_traffic_quota_and_rank_logs():
     assert os.path.basename(bench.rank_log_path(3)) == "bench_rank3.err"
     model, total, usable = bench.host_cpu_info()
     assert total >= usable >= 1 and isinstance(model, str)
+
+
+def test_launcher_watchdog_ends_a_hung_run_and_keeps_the_evidence(tmp_path, monkeypatch):
+    """First contact with N > 1 ranks happens on the driver's box: a rank that stops making progress (a
+    collective that never completes) must not leave `python bench.py --gpus N` waiting for the driver's kill.
+    A live rank whose log / stderr stay silent past --rank-timeout gets every rank terminated (killed if it
+    ignores that), exit code 124, and a verdict line; a rank that keeps writing is never taken for hung."""
+    sys.path.insert(0, ROOT)
+    import bench
+    monkeypatch.setattr(bench, "rank_log_path", lambda r: str(tmp_path / f"bench_rank{r}.err"))
+    now = [0.0]
+    reports = []
+
+    class Proc:
+        """rank 1 hangs forever (and ignores SIGTERM); the others would run for 1000 s, writing as they go"""
+        procs = []
+
+        def __init__(self, cmd, env, stdout, stderr=None):
+            self.rank = int(env["RANK"])
+            self.terminated = self.killed = False
+            Proc.procs.append(self)
+
+        def poll(self):
+            if self.killed:
+                return -9
+            if self.terminated and self.rank != 1:
+                return -15
+            return None
+
+        def terminate(self):
+            self.terminated = True
+
+        def kill(self):
+            self.killed = True
+
+    def evidence(rank):                    # every rank but 1 logs something new every 10 s of fake time
+        return (0, 0.0) if rank == 1 else (int(now[0] // 10), now[0] // 10)
+
+    def sleep(dt):
+        now[0] += 1.0                      # fake time: one second per poll
+
+    a = bench.parse(["--gpus", "4", "--rank-timeout", "30"])
+    rc = bench.launch_ranks(a, ["--gpus", "4"], environ={}, popen=Proc, clock=lambda: now[0], sleep=sleep,
+                            evidence=evidence, report=reports.append)
+    assert rc == 124
+    assert 30 < now[0] < 60                                                    # ended soon after the limit, not at 1000 s
+    assert all(p.terminated for p in Proc.procs) and Proc.procs[1].killed      # SIGTERM for all, SIGKILL for the deaf one
+    assert not any(p.killed for p in Proc.procs if p.rank != 1)
+    assert len(reports) == 1 and "[1]" in reports[0] and "silent" in reports[0]
+
+    # a slow but living run is left alone; --rank-timeout 0 switches the watchdog off
+    Proc.procs.clear()
+    now[0] = 0.0
+
+    class Slow(Proc):
+        def poll(self):
+            return 0 if now[0] > 200 else None
+    a = bench.parse(["--gpus", "2", "--rank-timeout", "30"])
+    assert bench.launch_ranks(a, ["--gpus", "2"], environ={}, popen=Slow, clock=lambda: now[0], sleep=sleep,
+                              evidence=lambda r: (int(now[0] // 10), 0.0), report=reports.append) == 0
+    assert len(reports) == 1
+    now[0] = 0.0
+    a = bench.parse(["--gpus", "2", "--rank-timeout", "0"])
+    assert bench.launch_ranks(a, ["--gpus", "2"], environ={}, popen=Slow, clock=lambda: now[0], sleep=sleep,
+                              evidence=lambda r: (0, 0.0), report=reports.append) == 0
+
+    # real processes: rank 1 sleeps "forever", the watchdog (1 s) ends the run; logs stay
+    probe = tmp_path / "probe.py"
+    probe.write_text("import os, sys, time\n"
+                     "r = int(os.environ['RANK'])\n"
+                     "time.sleep(600 if r == 1 else 0.1)\n")
+    real_popen = subprocess.Popen
+
+    def probe_popen(cmd, env, stdout, stderr=None):
+        return real_popen([sys.executable, str(probe)], env=env, stdout=subprocess.DEVNULL, stderr=stderr)
+    import time as _t
+    t0 = _t.monotonic()
+    a = bench.parse(["--gpus", "2", "--rank-timeout", "1"])
+    assert bench.launch_ranks(a, ["--gpus", "2"], environ=dict(os.environ), popen=probe_popen, report=reports.append) == 124
+    assert _t.monotonic() - t0 < 20
+    assert os.path.exists(str(tmp_path / "bench_rank1.err.stderr.log"))

@@ -124,7 +124,9 @@ def test_config4_64_streams_through_cpp_host_layer(streams64, streams, threads):
     h = s["held"]
     assert h["contexts"] == 1 and h["mem_pools"] == 1 and h["pipes"] == streams * threads
     assert h["hip_streams"] == streams * threads * 3 + 1 and h["hip_events"] == streams * threads * 3
-    assert streams * threads * 3 * (16 << 20) <= h["pinned_bytes"] <= streams * threads * 3 * (16 << 20) * 1.05
+    # staging is page-locked per batch on first use: every worker pinned at least its first batch, none more than 3
+    assert streams * threads * (16 << 20) <= h["pinned_bytes"] <= streams * threads * 3 * (16 << 20) * 1.05
+    assert streams * threads <= h["pinned_batches"] <= 3 * streams * threads
     print(f"\nconfig 4, {streams} streams x {threads} workers on one device: {s['frames_scanned']} frames in "
           f"{s['wall_us'] / 1e3:.0f} ms wall; held {h['contexts']} contexts, {h['hip_streams']} HIP streams, "
           f"{h['pinned_bytes'] / 2**20:.0f} MiB pinned, {h['device_bytes'] / 2**20:.1f} MiB device")
@@ -158,3 +160,23 @@ def test_config4_bad_environment_is_an_error_not_a_crash(streams64):
     r, jobs, s = _run(paths[:4], 4, 1, d, {"MTGPU_BATCH_MB": "abc"})
     assert r.returncode == 1 and jobs == [] and s["failed"] == 4
     assert r.stderr.count("configuration:") == 4
+
+
+def test_failed_video_does_not_hand_its_pipe_to_the_next_one(streams64):
+    """a worker's backend (context + pinned pipe) outlives a video (process_batch keeps it for the next
+    file).  When a collect fails — here injected ONCE in the process, with the batch's drain failing too, so the
+    batch is retired — the video fails, and the pipe, whose state is unknown, must not serve the next video: the
+    backend is marked dirty and rebuilt.  One stream x one worker over three files: exactly one fails, the other
+    two are bit-exact, one pipe was rebuilt."""
+    d, paths, cases = streams64
+    three = [pth for pth in paths if cases[pth][2]["do_cut"] >= 0][:3]
+    r, jobs, s = _run(three, 1, 1, d, {"MTGPU_INJECT_COLLECT_FAIL": "-2", "MTGPU_INJECT_ONCE": "1"})
+    assert r.returncode == 1 and s["failed"] == 1 and s["videos"] == 3
+    errs = [ln for ln in r.stderr.splitlines() if ln.startswith("error:")]
+    assert len(errs) == 1 and three[0] in errs[0] and "retired" in errs[0]
+    assert sorted(j["input"] for j in jobs) == sorted(three[1:])
+    for j in jobs:
+        pooled, want_seg, want_res, scanned = cases[j["input"]]
+        _check_job(j, pooled, want_seg, want_res)
+        assert j["frames_scanned"] == scanned
+    assert s["held"]["pipe_rebuilds"] == 1 and s["held"]["pipes"] == 1

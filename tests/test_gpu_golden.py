@@ -829,3 +829,54 @@ def test_scan_under_reference_parsed_configs(gpu_scanner_factory):
         some_motion += int(want.any())
         s.close()
     assert ran >= 25 and some_motion >= 5, (ran, some_motion)
+
+
+@pytest.mark.parametrize("layout", [m._abi.LAYOUT_COMPACT8 | m._abi.LAYOUT_ZERO_COPY, m._abi.LAYOUT_AOS40])
+def test_pipe_pins_staging_on_first_use(gpu_scanner_factory, monkeypatch, layout):
+    """Round 4: page-locking is the cost of creating a pipe (~0.2 ms per MiB, serialised across threads by the
+    driver), so a pipe pins ONE batch at creation and every other batch when mtgpu_pipe_acquire first hands it
+    out; MTGPU_PIPE_EAGER=1 restores pin-everything-at-creation.  Results do not depend on it."""
+    import ctypes as C
+    p = ob.params_from_config(1920, 1080, vectors_needed=1)
+    s = gpu_scanner_factory(p)
+    lib = m.load_library()
+
+    def stats(pipe):
+        st = m._abi.PipeStatsC()
+        m._abi.check(lib.mtgpu_pipe_get_stats(pipe._pipe, C.byref(st)))
+        return st
+    spec = synth.spec_1080p(seed=12, sub=1)
+    spec.events = [synth.Event(2, 20, 40, 30, 4, 3, 9, 2)]
+    mv, off, pts, sd = synth.gen_stream(spec, 24)
+    want = ob.scan_frames(p, mv, off, sd)
+    pipe = m.ScanPipe(s, 8160 * 4, 4, 3, layout=layout)
+    st = stats(pipe)
+    one = st.pinned_bytes
+    assert st.pinned_batches == 1 and st.n_buffers == 3 and one >= 8160 * 4 * (8 if layout & 1 == 0 else 40)
+    assert (st.device_bytes == 0) == bool(layout & m._abi.LAYOUT_ZERO_COPY)
+    a, b = C.c_void_p(), C.c_void_p()
+    m._abi.check(lib.mtgpu_pipe_acquire(pipe._pipe, C.byref(a)))          # the pinned one
+    assert stats(pipe).pinned_batches == 1
+    m._abi.check(lib.mtgpu_pipe_acquire(pipe._pipe, C.byref(b)))          # a second one while the first is held: pinned now
+    st = stats(pipe)
+    assert st.pinned_batches == 2 and st.pinned_bytes == 2 * one and st.pin_us > 0
+    m._abi.check(lib.mtgpu_pipe_release(pipe._pipe, a))
+    m._abi.check(lib.mtgpu_pipe_release(pipe._pipe, b))
+    # a whole stream through it (4 frames per batch -> up to 3 batches in flight -> all three get pinned)
+    for i in range(24):
+        fr = mv[int(off[i]):int(off[i + 1])]
+        pipe.feed(fr if sd[i] else None, float(pts[i]), tag=i)
+    got = pipe.drain()
+    assert [f for _, f, _ in got] == want.tolist() and want.sum() >= 10
+    st = stats(pipe)
+    assert 2 <= st.pinned_batches <= 3 and st.pinned_bytes == st.pinned_batches * one
+    pipe.close()
+    monkeypatch.setenv("MTGPU_PIPE_EAGER", "1")
+    pipe = m.ScanPipe(s, 8160 * 4, 4, 3, layout=layout)
+    st = stats(pipe)
+    assert st.pinned_batches == 3 and st.pinned_bytes == 3 * one
+    for i in range(24):
+        fr = mv[int(off[i]):int(off[i + 1])]
+        pipe.feed(fr if sd[i] else None, float(pts[i]), tag=i)
+    assert [f for _, f, _ in pipe.drain()] == want.tolist()
+    pipe.close()

@@ -1275,3 +1275,53 @@ def test_merge_extreme_finite_values(gpu_scanner_factory, job):
     for ts in lists:
         for mp in params:
             merge_case(s, rng.permutation(np.array(ts, dtype=np.float64)), mp, job)
+
+
+def test_device_offsets_precondition_check_opt_in(gpu_scanner_factory, monkeypatch):
+    """include/mtgpu.h: d_frame_off must be non-decreasing (frames = disjoint record ranges; a banded plan keeps
+    each frame's vote queue at the frame's own offset).  With MTGPU_CHECK_OFFSETS=1 (read at mtgpu_create) both
+    device entry points verify that on the device and return MT_ERR_INVALID naming the first offending frame,
+    before anything is scanned; well-formed offsets scan as usual — on the automatic 2-band plan of the 960x540
+    grid (shipped env) and on a single-tile plan; without the knob nothing is checked (asynchronous API)."""
+    import torch
+    monkeypatch.setenv("MTGPU_CHECK_OFFSETS", "1")
+    p, s = _fine_shipped_env_scanner(gpu_scanner_factory)
+    spec = synth.spec_4k_fine_dense(seed=5)
+    spec.events = [synth.Event(1, 3, 300, 100, 5, 4, 9, 3), synth.Event(3, 5, 640, 400, 4, 3, -7, 2)]
+    mv, off, pts, sd = synth.gen_stream(spec, 6)
+    want = ob.scan_frames(p, mv, off, sd)
+    d_mv = torch.from_numpy(mv.view(np.uint8).copy()).cuda()
+    d_sd = torch.from_numpy(sd.astype(np.uint8)).cuda()
+    good = torch.from_numpy(off.astype(np.int64)).cuda()
+    got = s.check_frames_device(d_mv, good, d_sd)
+    assert np.array_equal(got.cpu().numpy(), want) and want.sum() >= 2
+    bad = off.astype(np.int64).copy()
+    bad[3] = bad[2] - 1000                                    # frame 2 would end before it starts; frame 3 overlaps frame 1..2
+    flags = torch.full((6,), 7, dtype=torch.uint8, device="cuda")
+    with pytest.raises(m.MtgpuError) as ei:
+        s.check_frames_device(d_mv, torch.from_numpy(bad).cuda(), d_sd, flags=flags)
+    assert ei.value.code == m._abi.MT_ERR_INVALID and "frame_off[2] > frame_off[3]" in str(ei.value)
+    torch.cuda.synchronize()
+    assert flags.cpu().tolist() == [7] * 6                    # nothing was scanned
+    # the compact entry point checks too
+    rec8 = torch.from_numpy(m.pack_records(mv).view(np.uint8).copy()).cuda()
+    assert np.array_equal(s.check_frames_device_compact(rec8, good, d_sd).cpu().numpy(), want)
+    with pytest.raises(m.MtgpuError) as ei:
+        s.check_frames_device_compact(rec8, torch.from_numpy(bad).cuda(), d_sd)
+    assert ei.value.code == m._abi.MT_ERR_INVALID
+    # several bad entries: the FIRST one is named; single-tile plan
+    p2 = ob.params_from_config(1920, 1080)
+    s2 = gpu_scanner_factory(p2)
+    rng = np.random.RandomState(3)
+    mv2, off2, _ = synth.random_frames(rng, 3000, 300, 1920, 1080)
+    bad2 = off2.astype(np.int64).copy()
+    bad2[1500], bad2[2500] = bad2[1499] - 1, 0
+    with pytest.raises(m.MtgpuError) as ei:
+        s2.check_frames_device(torch.from_numpy(mv2.view(np.uint8).copy()).cuda(), torch.from_numpy(bad2).cuda())
+    assert "frame_off[1499] > frame_off[1500]" in str(ei.value)
+    # a context created without the knob does not check (and a single-tile plan tolerates the overlap: clamped ranges)
+    monkeypatch.delenv("MTGPU_CHECK_OFFSETS")
+    s3 = gpu_scanner_factory(p2)
+    got3 = s3.check_frames_device(torch.from_numpy(mv2.view(np.uint8).copy()).cuda(), torch.from_numpy(bad2).cuda())
+    torch.cuda.synchronize()
+    assert got3.numel() == 3000

@@ -319,3 +319,42 @@ def test_concat_list_text(host_probe):
     out = subprocess.run([host_probe, "concat", "/v/a b.mp4"], input=stdin, capture_output=True, text=True, check=True).stdout
     assert out == want
     assert m.concat_list([], "/x") == "" and m.concat_list(np.zeros((0, 2)), "/x") == ""
+    # fmt's {:.2f} prints EVERY digit of a huge value and never follows the C locale: neither may the C++ layer
+    # (it once formatted into char[64] with snprintf: 1e300 lost its tail and its newline; a decimal-comma
+    # locale would have printed "0,12")
+    big = [(1e300, 1.7976931348623157e308), (0.125, 1e60)]
+    want_big = m.concat_list(big, "/b")
+    assert want_big.count("\n") == 6 and ("inpoint " + "%.2f" % 1e300 + "\n") in want_big and len(want_big) > 600
+    stdin = "".join(f"{a!r} {b!r}\n" for a, b in big)
+    for loc in ("C", "de_DE.UTF-8", "fr_FR.UTF-8"):
+        out = subprocess.run([host_probe, "concat", "/b", "--setlocale"], input=stdin, capture_output=True, text=True,
+                             check=True, env=dict(os.environ, LC_ALL=loc)).stdout
+        assert out == want_big, loc
+
+
+def test_cpu_gate_and_cpu_limit(host_probe):
+    """The host layer's CPU budget: cpu_limit() follows the reference's detect_cpu_limit() order
+    (src/system.cpp:107-164: cgroup v2 cpu.max, cgroup v1 quota, cpuset, hardware threads — rounded up), and the
+    CpuGate never lets more workers fill batches at once than it has tokens (0 tokens = no gate)."""
+    def want_limit():
+        try:
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            if q != "max":
+                return -(-int(q) // int(per))
+        except OSError:
+            pass
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and per > 0:
+                return -(-q // per)
+        except (OSError, ValueError):
+            pass
+        return len(os.sched_getaffinity(0))
+    assert int(run(host_probe, ["cpulimit"])[0]) == want_limit() >= 1
+    peak, passes, waited, tokens = (int(x) for x in run(host_probe, ["gate", "3", "12", "20"])[0].split()[1::2])
+    assert peak <= 3 and passes == 240 and waited == 1 and tokens == 3
+    peak, passes, waited, tokens = (int(x) for x in run(host_probe, ["gate", "0", "8", "10"])[0].split()[1::2])
+    assert passes == 80 and waited == 0 and tokens == 0 and 1 <= peak <= 8
+    peak, passes, waited, tokens = (int(x) for x in run(host_probe, ["gate", "16", "4", "10"])[0].split()[1::2])
+    assert peak <= 4 and passes == 40 and waited == 0
