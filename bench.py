@@ -799,6 +799,12 @@ def _run_rank(a):
         stage("done")
         import faulthandler
         faulthandler.cancel_dump_traceback_later()
+        try:                                   # the hang log of a run that did not hang is empty: drop it
+            hang = rank_log_path(rank) + ".hang.log"
+            if os.path.exists(hang) and os.path.getsize(hang) == 0:
+                os.remove(hang)
+        except OSError:
+            pass
     scanner.close()
     del out
 

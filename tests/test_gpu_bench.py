@@ -66,7 +66,11 @@ def test_bench_two_ranks_rehearsal_gloo_same_device(tmp_path):
     logs = [p if os.path.exists(p) else os.path.join(ROOT, os.path.basename(p)) for p in logs]
     for r, p in enumerate(logs):                                   # every rank left its own evidence
         recs = [json.loads(ln) for ln in open(p)]
-        assert [x["stage"] for x in recs] == ["start", "timed"] and recs[1]["rank"] == r
+        # one line per stage (the launcher's watchdog reads their arrival as the rank's sign of life)
+        assert [x["stage"] for x in recs] == ["start", "process_group_ready", "workload_resident", "warm", "timed",
+                                              "line_printed" if r == 0 else "waiting_for_rank_0", "done"]
+        timed = [x for x in recs if x["stage"] == "timed"][0]
+        assert timed["rank"] == r and recs[0]["rank"] == r and timed["frames_scanned"] > 0
 
 
 def test_bench_rccl_branch_with_one_rank():
