@@ -12,6 +12,8 @@ int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 int hip_fail(hipError_t e, const char *what);
 
 int ctx_device(const mtgpu_ctx *c);
+// logical -> physical HIP device (identity unless MTGPU_ALIAS_DEVICES presents more logical devices than exist)
+int physical_device(int logical);
 // Launch the scan for a device-resident batch on `st`.
 // rec_bytes: MT_MV_BYTES (AVMotionVector records) or MT_COMPACT_BYTES (packed src/dst fields).
 int ctx_launch_scan(mtgpu_ctx *c, const void *d_mv, uint64_t n_records, const uint64_t *d_off,

@@ -79,6 +79,7 @@ int mtgpu_comm_create(int rank, int n_ranks, const void *id, int device, mtgpu_c
   *out = nullptr;
   if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(MT_ERR_INVALID, "rank %d of %d", rank, n_ranks);
   if (!load_rccl()) return fail(MT_ERR_DEVICE, "librccl.so.1 not available");
+  device = mtgpu::physical_device(device);
   hipError_t e = hipSetDevice(device);
   if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
   mtgpu_comm *c = new (std::nothrow) mtgpu_comm();

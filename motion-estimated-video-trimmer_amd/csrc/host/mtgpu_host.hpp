@@ -136,7 +136,10 @@ inline int cpu_limit() {
 // workers under a 16-CPU cgroup quota were each scheduled ~16 % of the time while "copying" (the quota is handed
 // to CPUs in slices; round 4, profiles/r04_host_feed_*.json), i.e. a copy-out that streams 37 GB/s per thread
 // when it runs delivered 2.7 GB/s per worker.  The gate keeps the runnable set at the CPU budget.
-// MTGPU_CPU_TOKENS: 0 = no gate, N = that many tokens, unset = cpu_limit().
+// MTGPU_CPU_TOKENS: 0 = no gate, N = that many tokens, unset = 3/4 of cpu_limit() (rounded up): the budget also has to
+// carry the HIP runtime's own threads and the wake-ups of the waiting workers — measured on a 16-CPU quota with 64
+// workers (profiles/r04_host_feed_ab_gate.json): no gate 84-99 k frames/s, 24 tokens 102 k, 16 tokens 115 k,
+// 12 tokens 135 k, 8 tokens 134 k.
 class CpuGate {
   std::mutex mu_;
   std::condition_variable cv_;
@@ -147,7 +150,7 @@ class CpuGate {
   static CpuGate &instance() {
     static CpuGate g([] {
       const char *e = std::getenv("MTGPU_CPU_TOKENS");
-      return e ? std::max(0, std::atoi(e)) : cpu_limit();
+      return e ? std::max(0, std::atoi(e)) : std::max(1, (3 * cpu_limit() + 3) / 4);
     }());
     return g;
   }

@@ -72,7 +72,8 @@ struct mtgpu_ctx {
   mt_scan_params params;
   mtgpu::ScanK k;
   mtgpu_plan plan;
-  int device;
+  int device;            // physical HIP device
+  int logical_device = 0;  // what the caller asked for (differs only under MTGPU_ALIAS_DEVICES)
   hipStream_t stream;    // private stream of the host-pointer entry points
   int variant = 0;       // MTGPU_VARIANT experiment knob
   int slices_request = 0;  // 0 = auto, else 1/2/4/8 (mtgpu_set_slices, MTGPU_FORCE_SLICES)
@@ -239,7 +240,7 @@ int make_plan(mtgpu_ctx *c, int lds_max, int cu_count) {
   c->plan.band_rows = k.band_rows;
   c->plan.lds_bytes = (int)lds;
   c->plan.counter_bits = fb;
-  c->plan.device = c->device;
+  c->plan.device = c->logical_device;
   c->plan.cu_count = cu_count;
   c->plan.chunk_rows = chunk_rows;
   c->variant = env_int("MTGPU_VARIANT", 0);
@@ -385,9 +386,25 @@ int launch_scan_on(mtgpu_ctx *c, const void *d_mv, uint64_t n_records, const uin
 
 }  // namespace
 
+namespace {
+// MTGPU_ALIAS_DEVICES=N (tests, rehearsals on a box with fewer GPUs than the target node): the library presents N
+// LOGICAL devices; logical device d runs on physical device d % (real count).  Everything above the C ABI — the
+// host layer's stream -> device assignment, one shared context and scratch pool per (device, parameters), pipes
+// per device — then takes its multi-device paths on a 1-GPU box.  Read once; 0 / unset = no aliasing.
+int alias_devices() {
+  static const int n = [] { const char *e = getenv("MTGPU_ALIAS_DEVICES"); return e ? std::max(0, atoi(e)) : 0; }();
+  return n;
+}
+}  // namespace
+
 namespace mtgpu {
 // (the host copy-out loop, pack_records, lives in pack_simd.cpp: a plain host TU with per-CPU dispatch)
 int ctx_device(const mtgpu_ctx *c) { return c->device; }
+int physical_device(int logical) {
+  int n = 0;
+  if (alias_devices() <= 0 || hipGetDeviceCount(&n) != hipSuccess || n < 1) return logical;
+  return logical >= 0 ? logical % n : logical;
+}
 int ctx_launch_scan(mtgpu_ctx *c, const void *d_mv, uint64_t n_records, const uint64_t *d_off,
                     const uint8_t *d_sd, uint32_t n_frames, uint8_t *d_flags, hipStream_t st, int rec_bytes) {
   return launch_scan_on(c, d_mv, n_records, d_off, d_sd, n_frames, d_flags, st, rec_bytes);
@@ -410,6 +427,7 @@ const char *mtgpu_last_error(void) { return g_err; }
 int mtgpu_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  if (n > 0 && alias_devices() > 0) return alias_devices();
   return n;
 }
 
@@ -445,7 +463,10 @@ int mtgpu_create(const mt_scan_params *params, int device, mtgpu_ctx **out) {
   if (e != hipSuccess || ndev < 1)
     return fail(MT_ERR_DEVICE, "no HIP device available (%s); this library has no CPU fallback",
                 e == hipSuccess ? "device count 0" : hipGetErrorString(e));
-  if (device < 0 || device >= ndev) return fail(MT_ERR_INVALID, "device %d outside [0,%d)", device, ndev);
+  const int logical_devices = alias_devices() > 0 ? alias_devices() : ndev;
+  if (device < 0 || device >= logical_devices) return fail(MT_ERR_INVALID, "device %d outside [0,%d)", device, logical_devices);
+  const int logical = device;
+  device = device % ndev;                    // (MTGPU_ALIAS_DEVICES: logical -> physical)
   HIP_TRY(hipSetDevice(device));
   int lds_max = 0, cus = 0;
   HIP_TRY(hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, device));
@@ -454,6 +475,7 @@ int mtgpu_create(const mt_scan_params *params, int device, mtgpu_ctx **out) {
   if (!c) return fail(MT_ERR_NOMEM, "out of host memory");
   c->params = *params;
   c->device = device;
+  c->logical_device = logical;
   c->lds_max = lds_max;
   c->stream = nullptr;
   rc = make_plan(c, lds_max, cus);
@@ -527,6 +549,7 @@ int mtgpu_plan_preview(const mt_scan_params *params, int lds_bytes_per_workgroup
   if (!tmp) return fail(MT_ERR_NOMEM, "out of host memory");
   tmp->params = *params;
   tmp->device = -1;
+  tmp->logical_device = -1;
   tmp->stream = nullptr;
   tmp->lds_max = lds_bytes_per_workgroup;
   rc = make_plan(tmp, lds_bytes_per_workgroup, cu_count);

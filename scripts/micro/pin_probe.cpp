@@ -79,6 +79,43 @@ int main() {
     first = false;
     std::fflush(stdout);
   }
+  std::printf("], \"concurrent_pipe_shaped_setup\": [");
+  // what mtgpu_pipe_create does per worker thread besides pinning: hipSetDevice in a fresh thread, 3 non-blocking
+  // streams, 3 events — T threads at once
+  first = true;
+  for (int T : {1, 16, 64}) {
+    std::vector<std::thread> th;
+    std::vector<double> t_dev(T, 0.0), t_str(T, 0.0), t_evt(T, 0.0), t_pin(T, 0.0);
+    std::vector<hipStream_t> st(T * 3, nullptr);
+    std::vector<hipEvent_t> ev(T * 3, nullptr);
+    std::vector<void *> ptr(T, nullptr);
+    double t0 = now();
+    for (int t = 0; t < T; ++t)
+      th.emplace_back([&, t] {
+        double a = now();
+        (void)hipSetDevice(0);
+        double b = now();
+        for (int i = 0; i < 3; ++i) (void)hipStreamCreateWithFlags(&st[t * 3 + i], hipStreamNonBlocking);
+        double c = now();
+        for (int i = 0; i < 3; ++i) (void)hipEventCreateWithFlags(&ev[t * 3 + i], hipEventDisableTiming | hipEventReleaseToSystem);
+        double d = now();
+        (void)hipHostMalloc(&ptr[t], 16ull << 20, hipHostMallocDefault);
+        double e = now();
+        t_dev[t] = b - a; t_str[t] = c - b; t_evt[t] = d - c; t_pin[t] = e - d;
+      });
+    for (auto &x : th) x.join();
+    double wall = now() - t0;
+    auto mean = [&](const std::vector<double> &v) { double s = 0; for (double x : v) s += x; return s / v.size() * 1e3; };
+    std::printf("%s{\"threads\": %d, \"wall_ms\": %.1f, \"mean_ms\": {\"hipSetDevice\": %.2f, \"3_streams\": %.2f, \"3_events\": %.2f, \"pin_16MiB\": %.2f}}",
+                first ? "" : ", ", T, wall * 1e3, mean(t_dev), mean(t_str), mean(t_evt), mean(t_pin));
+    first = false;
+    std::fflush(stdout);
+    double f0 = now();
+    for (auto s2 : st) if (s2) (void)hipStreamDestroy(s2);
+    for (auto e2 : ev) if (e2) (void)hipEventDestroy(e2);
+    for (void *p : ptr) if (p) (void)hipHostFree(p);
+    (void)f0;
+  }
   std::printf("]}\n");
   return 0;
 }
