@@ -81,7 +81,7 @@ typedef struct mtgpu_ctx_stats {
   uint64_t staging_device_bytes;  /* grow-only device buffers of the HOST-pointer entry points   */
   uint64_t pool_reserved_bytes;   /* device memory the scratch pool holds right now             */
   uint64_t pool_reserved_high;    /* its high-water mark                                        */
-  uint32_t hip_streams;           /* streams owned by the context (1)                           */
+  uint32_t hip_streams;           /* streams owned by the context: its own + the pipe-stream pool */
   uint32_t private_pool;          /* 1: scratch from the private pool; 0: device default pool   */
 } mtgpu_ctx_stats;
 int mtgpu_get_stats(mtgpu_ctx *ctx, mtgpu_ctx_stats *out);
@@ -296,13 +296,15 @@ typedef struct mtgpu_pipe_stats {
   uint64_t pinned_bytes;   /* page-locked host memory SO FAR: staging blocks + pts / tag / flag arrays */
   uint64_t device_bytes;   /* device mirrors of the staging (0 with MT_LAYOUT_ZERO_COPY)           */
   uint64_t submits;        /* batches submitted so far                                             */
-  uint32_t n_buffers;      /* staging batches = HIP streams = HIP events owned by the pipe         */
+  uint32_t n_buffers;      /* staging batches = HIP events owned by the pipe                        */
   int32_t layout;          /* MT_LAYOUT_* flags                                                    */
   uint64_t pin_us;         /* time spent page-locking staging (creation, first uses, growth)       */
   uint32_t pinned_batches; /* batches whose staging is pinned (the first at creation, the others   *
                             * when mtgpu_pipe_acquire first hands them out; MTGPU_PIPE_EAGER=1:    *
                             * all at creation)                                                     */
-  uint32_t _pad;
+  uint32_t hip_streams;    /* HIP streams OWNED by the pipe: 0 — batches run on the context's small stream   *
+                            * pool (MTGPU_PIPE_STREAMS, default 8; creating a stream costs ~3.5 ms,         *
+                            * serialised by the runtime) — or n_buffers with MTGPU_PIPE_STREAMS=0            */
 } mtgpu_pipe_stats;
 int mtgpu_pipe_get_stats(mtgpu_pipe *pipe, mtgpu_pipe_stats *out);
 

@@ -12,6 +12,8 @@ int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 int hip_fail(hipError_t e, const char *what);
 
 int ctx_device(const mtgpu_ctx *c);
+// a pooled stream of the context for one staging batch (nullptr: create your own)
+hipStream_t ctx_pipe_stream(mtgpu_ctx *c);
 // logical -> physical HIP device (identity unless MTGPU_ALIAS_DEVICES presents more logical devices than exist)
 int physical_device(int logical);
 // Launch the scan for a device-resident batch on `st`.

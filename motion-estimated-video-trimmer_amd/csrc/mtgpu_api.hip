@@ -85,6 +85,15 @@ struct mtgpu_ctx {
   int min_lds_kb = 0;    // MTGPU_MIN_LDS_KB: launch with at least this much LDS (caps workgroups per CU), 0 = automatic
   hipMemPool_t pool = nullptr;   // private stream-ordered pool for launch scratch (freed blocks stay cached)
   uint64_t merge_large_min = 4096;   // timestamp lists at least this long take the multi-workgroup merge (MTGPU_MERGE_LARGE_MIN)
+  // Streams of the pipes (host dispatcher): ONE small pool per context, handed to staging batches round-robin,
+  // instead of a stream per batch.  Creating a HIP stream costs ~3.5 ms and the runtime serialises it: 64 workers
+  // x 3 batches = 192 streams took 0.68 s of wall time and 0.35 s per worker — THE cost of creating a pipe
+  // (profiles/r04_pin_probe2.json) — while the runtime maps streams onto a handful of hardware queues anyway.
+  static constexpr int kMaxPipeStreams = 32;
+  hipStream_t pipe_streams[kMaxPipeStreams] = {};
+  int n_pipe_streams = 8;                // MTGPU_PIPE_STREAMS (0: every batch creates its own stream, as before round 4)
+  unsigned pipe_rr = 0;                  // next slot (guarded by pipe_mu)
+  std::mutex pipe_mu;
   std::mutex mu;         // guards the staging buffers below
   DevBuf d_mv, d_off, d_sd, d_flags, d_misc;
 };
@@ -255,6 +264,7 @@ int make_plan(mtgpu_ctx *c, int lds_max, int cu_count) {
   c->group_request = env_int("MTGPU_GROUP", 0);
   c->min_lds_kb = env_int("MTGPU_MIN_LDS_KB", 0);
   c->check_offsets = env_int("MTGPU_CHECK_OFFSETS", 0) != 0;
+  c->n_pipe_streams = std::min(std::max(env_int("MTGPU_PIPE_STREAMS", 8), 0), (int)mtgpu_ctx::kMaxPipeStreams);
   c->item_chunk = env_int("MTGPU_ITEM_CHUNK", 0);
   if (c->item_chunk < 0) c->item_chunk = 0;
   {
@@ -400,6 +410,20 @@ int alias_devices() {
 namespace mtgpu {
 // (the host copy-out loop, pack_records, lives in pack_simd.cpp: a plain host TU with per-CPU dispatch)
 int ctx_device(const mtgpu_ctx *c) { return c->device; }
+// A stream for one staging batch from the context's pool (created on first use of its slot; the caller has made
+// the context's device current), or nullptr when pooling is off or the creation failed (the batch then creates
+// a stream of its own).
+hipStream_t ctx_pipe_stream(mtgpu_ctx *c) {
+  if (c->n_pipe_streams <= 0) return nullptr;
+  std::lock_guard<std::mutex> lock(c->pipe_mu);
+  const unsigned slot = c->pipe_rr++ % (unsigned)c->n_pipe_streams;
+  if (!c->pipe_streams[slot] &&
+      hipStreamCreateWithFlags(&c->pipe_streams[slot], hipStreamNonBlocking) != hipSuccess) {
+    c->pipe_streams[slot] = nullptr;
+    (void)hipGetLastError();
+  }
+  return c->pipe_streams[slot];
+}
 int physical_device(int logical) {
   int n = 0;
   if (alias_devices() <= 0 || hipGetDeviceCount(&n) != hipSuccess || n < 1) return logical;
@@ -505,6 +529,8 @@ void mtgpu_destroy(mtgpu_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+  for (hipStream_t &ps : c->pipe_streams)            // (pipes are destroyed before their context: include/mtgpu.h)
+    if (ps) { (void)hipStreamSynchronize(ps); (void)hipStreamDestroy(ps); ps = nullptr; }
   if (c->pool) { (void)hipDeviceSynchronize(); (void)hipMemPoolDestroy(c->pool); }
   c->d_mv.release(); c->d_off.release(); c->d_sd.release(); c->d_flags.release(); c->d_misc.release();
   delete c;
@@ -516,6 +542,10 @@ int mtgpu_get_stats(mtgpu_ctx *c, mtgpu_ctx_stats *out) {
   std::lock_guard<std::mutex> lock(c->mu);
   out->staging_device_bytes = c->d_mv.cap + c->d_off.cap + c->d_sd.cap + c->d_flags.cap + c->d_misc.cap;
   out->hip_streams = c->stream ? 1u : 0u;
+  {
+    std::lock_guard<std::mutex> pl(c->pipe_mu);
+    for (hipStream_t ps : c->pipe_streams) out->hip_streams += ps ? 1u : 0u;
+  }
   out->private_pool = c->pool ? 1u : 0u;
   if (c->pool) {
     uint64_t cur = 0, high = 0;

@@ -67,7 +67,8 @@ struct mtgpu_batch {
   uint32_t cap_frames = 0, n_frames = 0;
   int rec_bytes = MT_COMPACT_BYTES;   // bytes per staged record: 8 (compact) or 40 (AoS)
   bool zero_copy = false;             // the scan reads the pinned staging (and writes the flags) over PCIe itself
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;       // from the context's pool (shared with other batches / pipes) or this batch's own
+  bool own_stream = false;
   hipEvent_t done = nullptr;
   int state = 0;   // 0 free, 1 filling, 2 in flight, 3 collected, 4 poisoned (never reused)
   mtgpu_pipe *owner = nullptr;
@@ -103,7 +104,7 @@ void free_batch(mtgpu_batch *b) {
   if (b->h_stage) (void)hipHostFree(b->h_stage);
   if (b->d_stage) (void)hipFree(b->d_stage);
   if (b->done) (void)hipEventDestroy(b->done);
-  if (b->stream) (void)hipStreamDestroy(b->stream);
+  if (b->stream && b->own_stream) (void)hipStreamDestroy(b->stream);
   delete b;
 }
 
@@ -188,7 +189,11 @@ int alloc_batch(mtgpu_batch **out, mtgpu_pipe *p, uint64_t max_records, uint32_t
   b->rec_bytes = p->rec_bytes;
   b->zero_copy = p->zero_copy;
   b->owner = p;
-  PIPE_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+  b->stream = mtgpu::ctx_pipe_stream(p->ctx);
+  if (!b->stream) {
+    PIPE_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    b->own_stream = true;
+  }
   // system-scope release at the event: the flag bytes a zero-copy scan wrote into pinned memory
   // are visible to the host thread that waits on it
   PIPE_TRY(hipEventCreateWithFlags(&b->done, hipEventDisableTiming | hipEventReleaseToSystem |
@@ -422,6 +427,7 @@ int mtgpu_pipe_get_stats(mtgpu_pipe *p, mtgpu_pipe_stats *out) {
       out->pinned_batches += 1;
     }
   out->pin_us = p->pin_us;
+  for (const mtgpu_batch *b : p->bufs) out->hip_streams += b->own_stream ? 1u : 0u;
   out->submits = (uint64_t)p->submits;
   out->n_buffers = (uint32_t)p->bufs.size();
   out->layout = (p->rec_bytes == MT_MV_BYTES ? MT_LAYOUT_AOS40 : MT_LAYOUT_COMPACT8) | (p->zero_copy ? MT_LAYOUT_ZERO_COPY : 0);

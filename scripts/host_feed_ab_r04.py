@@ -11,20 +11,35 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 exe = os.path.join(ROOT, "motion-estimated-video-trimmer_amd", "mtgpu_scan_file")
-SETTINGS = {
-    "scalar (round 3 loop), no gate": {"MTGPU_PACK": "scalar", "MTGPU_CPU_TOKENS": "0"},
-    "auto (vector loop, NT stores), no gate": {"MTGPU_CPU_TOKENS": "0"},
-    "vector loop, ordinary stores, no gate": {"MTGPU_PACK_NT": "0", "MTGPU_CPU_TOKENS": "0"},
-    "auto + prefetch 1 KiB, no gate": {"MTGPU_PACK_PREFETCH": "1024", "MTGPU_CPU_TOKENS": "0"},
-    "auto + blocking events, no gate": {"MTGPU_EVENT_BLOCKING": "1", "MTGPU_CPU_TOKENS": "0"},
-    "auto, gate = cpu limit": {},
-    "auto, gate 8": {"MTGPU_CPU_TOKENS": "8"},
-    "auto, gate 12": {"MTGPU_CPU_TOKENS": "12"},
-    "auto, gate 24": {"MTGPU_CPU_TOKENS": "24"},
-    "auto + prefetch 1 KiB, gate = cpu limit": {"MTGPU_PACK_PREFETCH": "1024"},
-    "scalar, gate = cpu limit": {"MTGPU_PACK": "scalar"},
-    "auto + blocking events, gate = cpu limit": {"MTGPU_EVENT_BLOCKING": "1"},
+SETS = {
+    # first call: copy-out loop x event wait, no gate existed yet
+    "gate": {
+        "scalar (round 3 loop), no gate": {"MTGPU_PACK": "scalar", "MTGPU_CPU_TOKENS": "0"},
+        "auto (vector loop, NT stores), no gate": {"MTGPU_CPU_TOKENS": "0"},
+        "vector loop, ordinary stores, no gate": {"MTGPU_PACK_NT": "0", "MTGPU_CPU_TOKENS": "0"},
+        "auto + prefetch 1 KiB, no gate": {"MTGPU_PACK_PREFETCH": "1024", "MTGPU_CPU_TOKENS": "0"},
+        "auto + blocking events, no gate": {"MTGPU_EVENT_BLOCKING": "1", "MTGPU_CPU_TOKENS": "0"},
+        "auto, gate = cpu limit": {"MTGPU_CPU_TOKENS": "16"},
+        "auto, gate 8": {"MTGPU_CPU_TOKENS": "8"},
+        "auto, gate 12": {"MTGPU_CPU_TOKENS": "12"},
+        "auto, gate 24": {"MTGPU_CPU_TOKENS": "24"},
+        "auto + prefetch 1 KiB, gate = cpu limit": {"MTGPU_PACK_PREFETCH": "1024", "MTGPU_CPU_TOKENS": "16"},
+        "scalar, gate = cpu limit": {"MTGPU_PACK": "scalar", "MTGPU_CPU_TOKENS": "16"},
+        "auto + blocking events, gate = cpu limit": {"MTGPU_EVENT_BLOCKING": "1", "MTGPU_CPU_TOKENS": "16"},
+    },
+    # the round's final host layer against each of its parts switched back
+    "final": {
+        "default (gate 3/4 of the CPU budget, 8 pooled streams, lazy pinning, vector copy-out)": {},
+        "a stream per batch (round 3)": {"MTGPU_PIPE_STREAMS": "0"},
+        "4 pooled streams": {"MTGPU_PIPE_STREAMS": "4"},
+        "16 pooled streams": {"MTGPU_PIPE_STREAMS": "16"},
+        "every batch pinned at creation (round 3)": {"MTGPU_PIPE_EAGER": "1"},
+        "no CPU gate (round 3)": {"MTGPU_CPU_TOKENS": "0"},
+        "scalar copy-out (round 3)": {"MTGPU_PACK": "scalar"},
+        "everything as in round 3": {"MTGPU_PIPE_STREAMS": "0", "MTGPU_PIPE_EAGER": "1", "MTGPU_CPU_TOKENS": "0", "MTGPU_PACK": "scalar"},
+    },
 }
+SETTINGS = SETS[os.environ.get("SET", "final")]
 only = os.environ.get("ONLY")
 if only:
     SETTINGS = {k: v for k, v in SETTINGS.items() if any(o.strip() in k for o in only.split(","))}

@@ -123,7 +123,9 @@ def test_config4_64_streams_through_cpp_host_layer(streams64, streams, threads):
     # (3 staging batches, each with its stream and event, one pinned slab) per worker thread
     h = s["held"]
     assert h["contexts"] == 1 and h["mem_pools"] == 1 and h["pipes"] == streams * threads
-    assert h["hip_streams"] == streams * threads * 3 + 1 and h["hip_events"] == streams * threads * 3
+    # the pipes' batches run on the context's pool of 8 streams (creating a stream costs ~3.5 ms, serialised by the
+    # runtime: 192 of them were the bulk of pipe set-up), events stay per batch
+    assert h["hip_streams"] == 8 + 1 and h["hip_events"] == streams * threads * 3
     # staging is page-locked per batch on first use: every worker pinned at least its first batch, none more than 3
     assert streams * threads * (16 << 20) <= h["pinned_bytes"] <= streams * threads * 3 * (16 << 20) * 1.05
     assert streams * threads <= h["pinned_batches"] <= 3 * streams * threads

@@ -880,3 +880,38 @@ def test_pipe_pins_staging_on_first_use(gpu_scanner_factory, monkeypatch, layout
         pipe.feed(fr if sd[i] else None, float(pts[i]), tag=i)
     assert [f for _, f, _ in pipe.drain()] == want.tolist()
     pipe.close()
+
+
+def test_pipe_batches_run_on_the_contexts_stream_pool(gpu_scanner_factory, monkeypatch):
+    """Round 4: a pipe no longer creates a HIP stream per batch (3.5 ms each, serialised by the runtime — 192 of
+    them were most of the 0.6 s a worker spent in mtgpu_pipe_create at 64 x 1); its batches take streams from a
+    pool of 8 owned by the context.  Four pipes of 3 batches on one context: 8 pool streams + the context's own,
+    none owned by a pipe, results as before; MTGPU_PIPE_STREAMS=0 (read at mtgpu_create) gives every batch its
+    own stream again."""
+    import ctypes as C
+    p = ob.params_from_config(1920, 1080, vectors_needed=1)
+    lib = m.load_library()
+    spec = synth.spec_1080p(seed=13, sub=1)
+    spec.events = [synth.Event(3, 15, 40, 30, 4, 3, 9, 2)]
+    mv, off, pts, sd = synth.gen_stream(spec, 20)
+    want = ob.scan_frames(p, mv, off, sd).tolist()
+
+    def pipe_stats(pipe):
+        st = m._abi.PipeStatsC()
+        m._abi.check(lib.mtgpu_pipe_get_stats(pipe._pipe, C.byref(st)))
+        return st
+    for pooled in (True, False):
+        if not pooled:
+            monkeypatch.setenv("MTGPU_PIPE_STREAMS", "0")
+        s = gpu_scanner_factory(p)
+        pipes = [m.ScanPipe(s, 8160 * 3, 3, 3) for _ in range(4)]
+        for i in range(20):                                     # four interleaved "decoder threads"
+            fr = mv[int(off[i]):int(off[i + 1])]
+            for pp in pipes:
+                pp.feed(fr if sd[i] else None, float(pts[i]), tag=i)
+        for pp in pipes:
+            assert [f for _, f, _ in pp.drain()] == want
+        assert [pipe_stats(pp).hip_streams for pp in pipes] == ([0] * 4 if pooled else [3] * 4)
+        assert s.stats()["hip_streams"] == (9 if pooled else 1)
+        for pp in pipes:
+            pp.close()
