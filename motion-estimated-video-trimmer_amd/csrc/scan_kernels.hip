@@ -37,8 +37,8 @@
 // Grids whose counters do not fit one LDS tile even packed are cut into ROW BANDS that the
 // SAME workgroup handles one after the other (template SPILL): the records are streamed from
 // HBM exactly once, during band 0; every surviving vote that a later band needs is appended to
-// a per-frame queue in global memory (4 bytes: gy << 16 | gx; wave-aggregated append, the tail
-// lives in LDS) and bands 1.. replay that queue instead of re-reading 40-byte records.  Typical
+// a per-frame queue in global memory (4 bytes: (run - 1) << 30 | gy << 15 | gx — one entry per RUN of up
+// to 4 same-cell records of a wave instruction; wave-aggregated append, the tail lives in LDS) and bands 1.. replay that queue instead of re-reading 40-byte records.  Typical
 // footage queues almost nothing (only votes above the threshold); the worst case (every record
 // votes, all into later bands) adds 4 B written + 4 B per later band read to each 40-B record.
 #if !defined(__HIP_DEVICE_COMPILE__) || defined(__gfx950__)
@@ -167,6 +167,47 @@ __device__ __forceinline__ void bump(unsigned int *cnt, unsigned int cell, unsig
   }
 }
 
+// n votes for one cell at once (a run of records of one wave instruction that landed in the same cell, or a
+// queue entry that stands for such a run).  Same final counter state as n single bumps: counters saturate at
+// `cap` and only `>= vectors_needed` is ever observed.
+template <int FB, int MODE>
+__device__ __forceinline__ void bump_n(unsigned int *cnt, unsigned int cell, unsigned int n, unsigned int cap) {
+  if constexpr (MODE == MODE_ADD32) {
+    atomicAdd(&cnt[cell], n);
+  } else if constexpr (MODE == MODE_UNARY && FB == 1) {
+    bump<FB, MODE>(cnt, cell, cap);
+  } else {
+    constexpr unsigned int FM = (FB >= 32) ? 0xffffffffu : ((1u << FB) - 1u);
+    const unsigned int bit = cell * FB;
+    unsigned int *w = &cnt[bit >> 5];
+    const unsigned int sh = bit & 31u;
+    if constexpr (MODE == MODE_UNARY) {
+      // thermometer field: set the next min(left, cap - j) clear bits with ONE returning OR; bits that another
+      // lane set in the meantime do not count for this one, which then continues above them.  Every updater
+      // only ever sets bits from the current fill level upwards, so the code stays contiguous.
+      unsigned int left = n < cap ? n : cap;
+      unsigned int j = (unsigned int)__popc((*w >> sh) & FM);
+      while (left != 0u && j < cap) {
+        const unsigned int take = min(left, cap - j);
+        const unsigned int m = ((1u << take) - 1u) << j;
+        const unsigned int fo = (atomicOr(w, m << sh) >> sh) & FM;
+        left -= (unsigned int)__popc(m & ~fo);
+        j = (unsigned int)__popc(fo | m);
+      }
+    } else {
+      unsigned int old = *w;
+      for (;;) {
+        const unsigned int cur = (old >> sh) & FM;
+        if (cur >= cap) break;
+        const unsigned int add = min(n, cap - cur);
+        const unsigned int seen = atomicCAS(w, old, old + (add << sh));
+        if (seen == old) break;
+        old = seen;
+      }
+    }
+  }
+}
+
 // Packed counter word -> one bit per field (32 / FB bits): is the cell active?
 template <int FB, int MODE>
 __device__ __forceinline__ unsigned int active_bits(unsigned int x, unsigned int vn) {
@@ -260,21 +301,45 @@ __device__ __forceinline__ void vote(const MvFields m, const ScanK &k, int t0, i
   // 0 <= gx < gw and y_lo <= gy < y_hi (:262) as two unsigned compares (y_hi >= y_lo by construction)
   const bool in = (mag >= k.thr) & ((unsigned int)gx < (unsigned int)k.gw) &
                   ((unsigned int)(gy - k.y_lo) < (unsigned int)(k.y_hi - k.y_lo));
-  // a single tile tracks every analysed row; only a band (SPILL) has to test its own rows
-  bool mine = in;
-  if constexpr (SPILL) mine = in & ((unsigned int)(gy - t0) < (unsigned int)(t1 - t0));
-  if (mine) bump<FB, MODE>(cnt, (unsigned int)((gy - t0) * k.gw + gx), k.vec_need);
-  if constexpr (SPILL) {
-    // wave-aggregated append: one returning LDS add per wave instruction, contiguous stores
-    const bool qv = in & (gy >= sq.q_lo);
-    const unsigned long long qm = __ballot(qv);
-    if (qm != 0ull) {
-      const int lane = (int)(threadIdx.x & 63u);
-      const int leader = __ffsll((long long)qm) - 1;
-      unsigned int base = 0u;
-      if (lane == leader) base = atomicAdd(sq.tail, (unsigned int)__popcll(qm));
-      base = (unsigned int)__shfl((int)base, leader);
-      if (qv) sq.q[base + (unsigned int)__popcll(qm & ((1ull << lane) - 1ull))] = ((unsigned int)gy << 16) | (unsigned int)gx;
+  if constexpr (!SPILL && (MODE == MODE_ADD32 || (MODE == MODE_UNARY && FB == 1))) {
+    // fire-and-forget LDS atomics (32-bit add, 1-bit or): a single tile tracks every analysed row
+    if (in) bump<FB, MODE>(cnt, (unsigned int)((gy - t0) * k.gw + gx), k.vec_need);
+  } else {
+    // Returning LDS atomics (thermometer / CAS fields) and the spill queue: RUNS of records that one wave
+    // instruction maps to the same cell — codecs export several vectors per block (two prediction directions,
+    // partitions), in stream order — vote once, with their count: on a frame where every record votes, the 4
+    // records of a block otherwise queue up on ONE LDS word four times over (8 cells of a 4-bit form share a
+    // word), and each would append its own queue entry.  A wave instruction without a voter costs one ballot.
+    const unsigned long long any = __ballot(in);
+    if (any == 0ull) return;
+    const int lane = (int)(threadIdx.x & 63u);
+    const unsigned int key = in ? (((unsigned int)gy << 15) | (unsigned int)gx) : 0xffffffffu;   // gx, gy < 32768
+    const unsigned int prev = (unsigned int)__shfl_up((int)key, 1);
+    // a queue entry carries a run of at most 4 (two spare bits): where a field can count beyond 4, runs are cut
+    // every 4 lanes so that no vote is lost to the entry format
+    const unsigned long long forced = (k.vec_need > 4u) ? 0x1111111111111111ull : 1ull;
+    // vote() is also called under divergence (head records, tails): a lane that is switched off ends the run
+    // below it, and the lane above it starts one (what __shfl_up brings from an inactive lane is undefined)
+    const unsigned long long off = ~__ballot(true);
+    const unsigned long long heads = __ballot(key != prev) | forced | off | (off << 1);
+    const bool head = ((heads >> lane) & 1ull) != 0ull;
+    const unsigned long long above = (lane < 63) ? (heads >> (lane + 1)) : 0ull;
+    const unsigned int run = above ? (unsigned int)__ffsll((long long)above) : (unsigned int)(64 - lane);
+    bool mine = in & head;                       // a band (SPILL) has to test its own rows
+    if constexpr (SPILL) mine = mine & ((unsigned int)(gy - t0) < (unsigned int)(t1 - t0));
+    if (mine) bump_n<FB, MODE>(cnt, (unsigned int)((gy - t0) * k.gw + gx), run, k.vec_need);
+    if constexpr (SPILL) {
+      // wave-aggregated append: one returning LDS add per wave instruction, contiguous stores;
+      // entry = (run - 1) << 30 | gy << 15 | gx
+      const bool qv = in & head & (gy >= sq.q_lo);
+      const unsigned long long qm = __ballot(qv);
+      if (qm != 0ull) {
+        const int leader = __ffsll((long long)qm) - 1;
+        unsigned int base = 0u;
+        if (lane == leader) base = atomicAdd(sq.tail, (unsigned int)__popcll(qm));
+        base = (unsigned int)__shfl((int)base, leader);
+        if (qv) sq.q[base + (unsigned int)__popcll(qm & ((1ull << lane) - 1ull))] = ((min(run, 4u) - 1u) << 30) | key;
+      }
     }
   }
 }
@@ -528,14 +593,14 @@ __device__ __forceinline__ void scan_item(
         for (int u = 0; u < 4; ++u) e[u] = sq.q[i + (unsigned int)u * BLOCK];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const int gy = (int)(e[u] >> 16), gx = (int)(e[u] & 0xffffu);
-          if (gy >= t0 && gy < t1) bump<FB, MODE>(cnt, (unsigned int)((gy - t0) * k.gw + gx), k.vec_need);
+          const int gy = (int)((e[u] >> 15) & 0x7fffu), gx = (int)(e[u] & 0x7fffu);
+          if (gy >= t0 && gy < t1) bump_n<FB, MODE>(cnt, (unsigned int)((gy - t0) * k.gw + gx), (e[u] >> 30) + 1u, k.vec_need);
         }
       }
       for (; i < nq; i += BLOCK) {
         const unsigned int e = sq.q[i];
-        const int gy = (int)(e >> 16), gx = (int)(e & 0xffffu);
-        if (gy >= t0 && gy < t1) bump<FB, MODE>(cnt, (unsigned int)((gy - t0) * k.gw + gx), k.vec_need);
+        const int gy = (int)((e >> 15) & 0x7fffu), gx = (int)(e & 0x7fffu);
+        if (gy >= t0 && gy < t1) bump_n<FB, MODE>(cnt, (unsigned int)((gy - t0) * k.gw + gx), (e >> 30) + 1u, k.vec_need);
       }
     }
     __syncthreads();
