@@ -38,6 +38,13 @@ SETS = {
         "scalar copy-out (round 3)": {"MTGPU_PACK": "scalar"},
         "everything as in round 3": {"MTGPU_PIPE_STREAMS": "0", "MTGPU_PIPE_EAGER": "1", "MTGPU_CPU_TOKENS": "0", "MTGPU_PACK": "scalar"},
     },
+    # does the 16-MiB batch of round 3 (chosen while the workers were throttled) still pay?
+    "batch": {
+        "16 MiB batches (default)": {},
+        "8 MiB batches": {"MTGPU_BATCH_MB": "8"},
+        "4 MiB batches": {"MTGPU_BATCH_MB": "4"},
+        "2 MiB batches": {"MTGPU_BATCH_MB": "2"},
+    },
 }
 SETTINGS = SETS[os.environ.get("SET", "final")]
 only = os.environ.get("ONLY")

@@ -1325,3 +1325,97 @@ def test_device_offsets_precondition_check_opt_in(gpu_scanner_factory, monkeypat
     got3 = s3.check_frames_device(torch.from_numpy(mv2.view(np.uint8).copy()).cuda(), torch.from_numpy(bad2).cuda())
     torch.cuda.synchronize()
     assert got3.numel() == 3000
+
+
+def _run_frames(rng, width, height, shift, vec, n_frames, margin_rows, totals=None, d=3):
+    """Frames made of RUNS: consecutive records that land in the same cell (what a codec emits for one block: two
+    prediction directions, partitions).  Every frame holds 1-3 pairs of 4-neighbouring cells; a cell's votes
+    (vec - 1, vec, vec + 1 or hundreds: the flag hinges on the exact count) arrive as several runs of random length,
+    scattered at random positions — hence at every lane alignment and across wave / step boundaries — through a
+    stream of records below the threshold."""
+    gw, gh = (width + (1 << shift) - 1) >> shift, (height + (1 << shift) - 1) >> shift
+    totals = totals or [max(vec - 1, 0), vec, vec + 1, 5 * vec + 64, 700]
+    frames = []
+    for _ in range(n_frames):
+        runs = []                                            # (cx, cy, length)
+        for _ in range(int(rng.randint(1, 4))):
+            gx, gy = int(rng.randint(1, gw - 2)), int(rng.randint(margin_rows, gh - margin_rows - 1))
+            for (cx, cy) in ((gx, gy), (gx + 1, gy) if rng.rand() < 0.5 else (gx, gy + 1)):
+                left = int(totals[rng.randint(0, len(totals))])
+                while left > 0:
+                    n = min(left, int(rng.choice([1, 1, 2, 3, 4, 5, 7, 8, 9, 31, 32, 33, 63, 64, 65, 130])))
+                    runs.append((cx, cy, n))
+                    left -= n
+        order = rng.permutation(len(runs))
+        recs = []
+        for i in order:
+            cx, cy, n = runs[i]
+            k = int(rng.choice([0, 0, 1, 2, 3, 5, 17, 60, 64, 200]))
+            recs += [(int(rng.randint(0, width)), int(rng.randint(0, height)), 0)] * 0
+            fx, fy = rng.randint(0, width, size=k), rng.randint(0, height, size=k)
+            recs += [(int(a), int(b), 0) for a, b in zip(fx, fy)]
+            x = (cx << shift) + rng.randint(0, 1 << shift, size=n)
+            y = (cy << shift) + rng.randint(0, 1 << shift, size=n)
+            recs += [(int(a), int(b), d) for a, b in zip(x, y)]
+        arr = np.array(recs, dtype=np.int64).reshape(-1, 3)
+        mv = np.zeros(len(arr), dtype=m.MV_DTYPE)
+        mv["dst_x"], mv["dst_y"] = arr[:, 0], arr[:, 1]
+        mv["src_x"], mv["src_y"] = arr[:, 0] - arr[:, 2], arr[:, 1]
+        frames.append(mv)
+    return frames
+
+
+@pytest.mark.parametrize("force_fb,vec", [(2, 1), (2, 2), (4, 3), (4, 4), (8, 5), (8, 8), (108, 9), (108, 40), (32, 4)])
+def test_same_cell_runs_every_length_and_alignment(gpu_scanner_factory, force_fb, vec):
+    """Round 4: runs of records that one wave instruction maps to the same cell vote once, with their count
+    (scan_kernels.hip: vote / bump_n).  Runs of every length from 1 to beyond a wave at every lane alignment, across
+    wave-instruction and streaming-step boundaries, in the divergent head / tail code, with cells ending exactly one
+    vote short of / at / above VECTORS_NEEDED, for every packed counter form (2 / 4 / 8-bit thermometer, 8-bit CAS;
+    where a field counts beyond 4 the runs are cut every 4 lanes) and the 32-bit form as control — against the
+    oracle, as 40-byte and as compact records."""
+    import torch
+    p = ob.params_from_config(1920, 1080, vectors_needed=vec, clusters_needed=2, mv_threshold_sq=4.0)
+    s = gpu_scanner_factory(p, force_fb=force_fb)
+    rng = np.random.RandomState(1000 * force_fb + vec)
+    frames = _run_frames(rng, 1920, 1080, 4, vec, 96, 3)
+    b = m.FrameBatch.from_frames(frames)
+    want = assert_scan_parity(s, p, b.mv, b.frame_off, b.has_sd)
+    assert 5 < want.sum() < len(want) - 5
+    rec8 = torch.from_numpy(m.pack_records(b.mv).view(np.uint8).copy()).cuda()
+    got8 = s.check_frames_device_compact(rec8, torch.from_numpy(b.frame_off.astype(np.int64)).cuda(),
+                                         torch.from_numpy(b.has_sd.astype(np.uint8)).cuda())
+    assert np.array_equal(got8.cpu().numpy(), want)
+
+
+def test_same_cell_runs_across_the_band_seam(gpu_scanner_factory):
+    """The same on the automatic 2-band plan of the 960x540 grid (4-bit fields, VECTORS_NEEDED 4): a queue entry
+    now stands for a run of up to 4 records — cells in the seam rows 268..271 (band 1 sees their votes only through
+    replayed entries) collect 3 / 4 / 5 / many votes in runs of 1..130 records; every flag as the oracle says."""
+    p, s = _fine_shipped_env_scanner(gpu_scanner_factory)
+    rng = np.random.RandomState(77)
+    frames = []
+    for trial in range(64):
+        runs = []
+        for _ in range(int(rng.randint(1, 3))):
+            gx = int(rng.randint(1, 957))
+            gy = int(rng.choice([268, 269, 270, 300, 100]))
+            for (cx, cy) in ((gx, gy), (gx, gy + 1)):
+                left = int(rng.choice([3, 4, 5, 84, 700]))
+                while left > 0:
+                    n = min(left, int(rng.choice([1, 1, 2, 3, 4, 5, 8, 9, 64, 65, 130])))
+                    runs.append((cx, cy, n))
+                    left -= n
+        recs = []
+        for i in rng.permutation(len(runs)):
+            cx, cy, n = runs[i]
+            k = int(rng.choice([0, 1, 3, 64, 700]))
+            recs += [(int(a), int(b), 1) for a, b in zip(rng.randint(0, 3840, size=k), rng.randint(0, 2160, size=k))]
+            recs += [((cx << 2) + int(rng.randint(0, 4)), (cy << 2) + int(rng.randint(0, 4)), 3) for _ in range(n)]
+        arr = np.array(recs, dtype=np.int64).reshape(-1, 3)
+        mv = np.zeros(len(arr), dtype=m.MV_DTYPE)
+        mv["dst_x"], mv["dst_y"] = arr[:, 0], arr[:, 1]
+        mv["src_x"], mv["src_y"] = arr[:, 0] - arr[:, 2], arr[:, 1]
+        frames.append(mv)
+    b = m.FrameBatch.from_frames(frames)
+    want = assert_scan_parity(s, p, b.mv, b.frame_off, b.has_sd)
+    assert 5 < want.sum() < len(want) - 5

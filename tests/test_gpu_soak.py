@@ -56,6 +56,11 @@ def test_soak_random_parity(gpu_scanner_factory):
         n_frames = int(rng.choice([3, 17, 64, 300]))
         mv, off, sd = synth.random_frames(rng, n_frames, int(rng.choice([200, 3000, 20000, 20000 if n_frames > 64 else 60000])), w, h,
                                           hot=float(rng.choice([0.05, 0.5, 0.95])))
+        if it % 2 == 0 and len(mv):                   # runs: every record repeated 1..6 times back to back (a block's
+            r = rng.randint(1, 7, size=len(mv))         # several vectors) — the run-aggregated vote path of packed forms
+            csum = np.concatenate([[0], np.cumsum(r)])
+            off = csum[off.astype(np.int64)].astype(np.uint64)
+            mv = np.repeat(mv, r)
         want = ob.scan_frames(p, mv, off, sd, nthreads=8)
         for _ in range(2):                              # twice: warm caches, reused workspaces
             got = s.check_frames(m.FrameBatch(mv, off, None, sd))
