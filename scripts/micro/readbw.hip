@@ -75,7 +75,36 @@ void run(const unsigned char *d, unsigned long long total, unsigned long long ch
          total / (ts[ts.size() / 2] * 1e-3) / 1e9);
 }
 
+// READBW_HOST=1: the same kernels reading PINNED HOST memory over PCIe (what a zero-copy staging batch is to the
+// scan kernel): which load shape / workgroup count pulls the most over the link?  READBW_MB = buffer size (default 64).
+static int host_sweep() {
+  const unsigned long long mb = getenv("READBW_MB") ? strtoull(getenv("READBW_MB"), nullptr, 10) : 64ull;
+  const unsigned long long total = mb * 1024 * 1024;
+  unsigned char *h = nullptr, *d = nullptr; unsigned int *sink;
+  if (hipHostMalloc(reinterpret_cast<void **>(&h), total + 4096, hipHostMallocDefault) != hipSuccess) return 1;
+  for (unsigned long long i = 0; i < total; i += 8) *reinterpret_cast<unsigned long long *>(h + i) = i * 0x9E3779B97F4A7C15ull;
+  (void)hipHostGetDevicePointer(reinterpret_cast<void **>(&d), h, 0);
+  (void)hipMalloc(&sink, 64);
+  const unsigned long long K = 1024;
+  printf("pinned host buffer %llu MiB, read by the GPU over PCIe\n", mb);
+  // compact frames are 255 KB, 40-byte frames 1275 KB: one workgroup per frame
+  run<512, 4, true, 0>(d, total, 255 * K, sink, "host x4 contiguous nt (compact)");
+  run<512, 4, false, 0>(d, total, 255 * K, sink, "host x4 contiguous default");
+  run<512, 8, true, 0>(d, total, 255 * K, sink, "host x4 contiguous nt");
+  run<256, 4, true, 0>(d, total, 255 * K, sink, "host x4 contiguous nt");
+  run<1024, 4, true, 0>(d, total, 255 * K, sink, "host x4 contiguous nt");
+  run<512, 4, true, 0>(d, total, 64 * K, sink, "host x4 contiguous nt");
+  run<512, 4, true, 0>(d, total, 1275 * K, sink, "host x4 contiguous nt");
+  run<512, 4, true, 0>(d, total, 16 * K, sink, "host x4 contiguous nt");
+  run<512, 4, true, 1>(d, total, 1305600, sink, "host x3 @ stride 40 nt (aos40)");
+  run<512, 4, false, 1>(d, total, 1305600, sink, "host x3 @ stride 40 default");
+  run<512, 4, true, 1>(d, total, 1305600 / 5, sink, "host x3 @ stride 40 nt");
+  run<512, 8, true, 1>(d, total, 1305600, sink, "host x3 @ stride 40 nt");
+  return 0;
+}
+
 int main() {
+  if (getenv("READBW_HOST")) return host_sweep();
   const unsigned long long gb = getenv("READBW_GB") ? strtoull(getenv("READBW_GB"), nullptr, 10) : 5ull;
   const unsigned long long total = gb * 1024 * 1024 * 1024 + 40ull * 1000;
   unsigned char *d; unsigned int *sink;
