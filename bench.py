@@ -324,9 +324,14 @@ def host_fed_leg(spec, mv, off):
     exe = os.path.join(ROOT, "motion-estimated-video-trimmer_amd", "mtgpu_scan_file")
     if not os.path.exists(exe):
         return {"error": "mtgpu_scan_file not built"}
-    n, reps, workers = 12, 500, min(16, len(os.sched_getaffinity(0)))
+    # Run lengths (round 4): the rate is measured from "all workers initialised" to the last result, and a pipe
+    # page-locks its 2nd and 3rd batch on first use, i.e. INSIDE that window (16 workers x 2 x 16 MiB = 0.1 s at the
+    # driver's ~5 GB/s): rounds 2-3 ran 6000 frames (35 ms of work), which now measures the page-locking, not the feed
+    n, workers = 12, min(16, len(os.sched_getaffinity(0)))
+    reps_of = {"compact8_zero_copy": 10000, "aos40_copy": 3000}
     frames = [mv[int(off[i]):int(off[i + 1])] for i in range(1, 1 + n)]       # P-frames 1..12 of the tile
-    out = {"source": f"{n}-frame 1080p dense8x8 stream repeated {reps}x ({n * reps} frames), cache-resident",
+    out = {"source": f"{n}-frame 1080p dense8x8 stream repeated {reps_of['compact8_zero_copy']}x / {reps_of['aos40_copy']}x "
+                     f"({n * reps_of['compact8_zero_copy']} / {n * reps_of['aos40_copy']} frames), cache-resident",
            "workers": workers, "gpus": 1, "front_end": "mtgpu_scan_file (C++ host layer: chunks -> pinned pipe -> scan -> merge)"}
     d = "/dev/shm" if os.path.isdir("/dev/shm") else None
     with tempfile.TemporaryDirectory(dir=d) as tmp:
@@ -339,6 +344,7 @@ def host_fed_leg(spec, mv, off):
             # one GPU only (the host layer would spread its workers over every visible device)
             env["HIP_VISIBLE_DEVICES"] = (os.environ.get("HIP_VISIBLE_DEVICES") or "0").split(",")[0]
             best = 0.0
+            reps = reps_of[name]
             for _ in range(2):
                 r = subprocess.run([exe, path, "--threads", str(workers), "--repeat", str(reps)], capture_output=True,
                                    text=True, env=env, timeout=120)

@@ -572,6 +572,9 @@ class GpuMotionScanner {   // public shape of MotionScanner (motion_scanner.hpp:
     auto us = [](clk::time_point a, clk::time_point b) {
       return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
     std::vector<double> ts;
+    // however this call is left — also by an exception out of the FrameSource — the CPU token goes back: a worker
+    // that died holding it would starve the others (with one token: for good)
+    struct TokenGuard { GpuMotionScanner &s; ~TokenGuard() { s.drop_token(); } } token_guard{*this};
     const double time_base = src_.time_base();
     const double video_fps = src_.fps();
     const double target = Config::target_fps();

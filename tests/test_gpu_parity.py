@@ -1419,3 +1419,23 @@ def test_same_cell_runs_across_the_band_seam(gpu_scanner_factory):
     b = m.FrameBatch.from_frames(frames)
     want = assert_scan_parity(s, p, b.mv, b.frame_off, b.has_sd)
     assert 5 < want.sum() < len(want) - 5
+
+
+def test_throwing_decoder_fails_its_video_and_returns_the_cpu_token(tmp_path):
+    """Round 4 (CpuGate): an exception out of FrameSource::next() reaches the worker while it holds a half-filled
+    staging batch and a CPU token.  The video must fail with the decoder's message, and the token must come back —
+    with MTGPU_CPU_TOKENS=1 the other two workers would otherwise wait for it for ever (the test would time out).
+    The same scene without the fault scans to the end."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.dirname(m.LIB_PATH)
+    exe = str(tmp_path / "throwing_source")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-I" + os.path.join(root, "include"),
+                           "-I" + os.path.join(pkg, "csrc", "host"), os.path.join(root, "tests", "cpp", "throwing_source.cpp"),
+                           "-o", exe, "-L" + pkg, "-lmtgpu", "-lpthread", "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib"])
+    env = dict(os.environ, MTGPU_CPU_TOKENS="1", CHUNK_DURATION_SEC="10", TARGET_FPS="0", VECTORS_NEEDED="1")
+    out = subprocess.run([exe, "3", "777"], env=env, capture_output=True, text=True, timeout=120).stdout
+    assert out.startswith("rc 1 ") and "tokens 1 " in out and "decoder lost the stream at frame 777" in out, out
+    out = subprocess.run([exe, "3", "-1"], env=env, capture_output=True, text=True, timeout=120).stdout
+    assert out.startswith("rc 0 motion 700 tokens 1 "), out          # frames 100..199, 300..399, ...: 7 x 100 moving frames
