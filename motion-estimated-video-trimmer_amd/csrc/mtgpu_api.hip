@@ -444,7 +444,7 @@ extern "C" int mtgpu_debug_set_phase_times(void *p) {      // developer build on
 
 extern "C" {
 
-const char *mtgpu_version(void) { return "mtgpu 0.3 (gfx950 MV scan + segment merge)"; }
+const char *mtgpu_version(void) { return "mtgpu 0.4 (gfx950 MV scan + segment merge)"; }
 
 const char *mtgpu_last_error(void) { return g_err; }
 
