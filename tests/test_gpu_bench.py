@@ -82,3 +82,34 @@ def test_bench_rccl_branch_with_one_rank():
     _check_line(d, 1, 600)
     assert "RCCL all_gather" in d["config"]["step"]
     assert d["distinct_devices"] == 1 and d["ranks"][0]["pci_bus_id"]
+
+
+def test_bench_under_torchrun_exactly_as_the_driver_launches_it():
+    """For N > 1 the driver does not call `python bench.py --gpus N` (bench.py's own launcher) but
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py
+    --gpus N --steps K --warmup W`: WORLD_SIZE is already set, so bench.py is ONE rank and starts nothing.  The same
+    command line here with two gloo ranks on the one device (RCCL refuses two ranks on one device): one JSON line on
+    rank 0's stdout, `n_gpus` 2, both ranks' stage logs complete."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
+           "--same-device"] + QUICK
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    _check_line(d, 2, 600)
+    assert "all_gather" in d["config"]["step"]
+    logs = [os.path.join(ROOT, "gpurun_out", f"bench_rank{k}.err") for k in (0, 1)]
+    logs = [p if os.path.exists(p) else os.path.join(ROOT, os.path.basename(p)) for p in logs]
+    for k, p in enumerate(logs):
+        stages = [json.loads(ln)["stage"] for ln in open(p)]
+        assert stages[0] == "start" and stages[-1] == "done" and "timed" in stages, (k, stages)
