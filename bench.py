@@ -196,7 +196,9 @@ def launch_ranks(a, argv, environ=None, popen=subprocess.Popen, clock=time.monot
                 killed_at = now
         if pending and limit > 0 and killed_at is None:
             silent = {r: now - seen[r][1] for r in pending}
-            hung = [r for r, dt in silent.items() if dt > limit]
+            # a rank that has not written anything yet is still importing torch / paging the image in (minutes on a
+            # fresh box, longer with N ranks at once): it gets twice the limit before it counts as hung
+            hung = [r for r, dt in silent.items() if dt > (limit if seen[r][0][0] > 0 else 2 * limit)]
             if hung:
                 report(f"bench launcher: rank(s) {hung} silent for more than {limit:.0f} s (no new line in "
                        f"bench_rank*.err, no stderr) — taken to be hung; terminating all {len(pending)} live ranks. "

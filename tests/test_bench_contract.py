@@ -154,8 +154,8 @@ def test_launcher_watchdog_ends_a_hung_run_and_keeps_the_evidence(tmp_path, monk
         def kill(self):
             self.killed = True
 
-    def evidence(rank):                    # every rank but 1 logs something new every 10 s of fake time
-        return (0, 0.0) if rank == 1 else (int(now[0] // 10), now[0] // 10)
+    def evidence(rank):                    # every rank but 1 logs something new every 10 s of fake time; rank 1 wrote
+        return (5, 1.0) if rank == 1 else (int(now[0] // 10), now[0] // 10)      # its "start" line and then nothing
 
     def sleep(dt):
         now[0] += 1.0                      # fake time: one second per poll
@@ -168,6 +168,15 @@ def test_launcher_watchdog_ends_a_hung_run_and_keeps_the_evidence(tmp_path, monk
     assert all(p.terminated for p in Proc.procs) and Proc.procs[1].killed      # SIGTERM for all, SIGKILL for the deaf one
     assert not any(p.killed for p in Proc.procs if p.rank != 1)
     assert len(reports) == 1 and "[1]" in reports[0] and "silent" in reports[0]
+
+    # a rank that never wrote a byte (still importing torch on a cold box) gets twice the limit
+    Proc.procs.clear()
+    now[0] = 0.0
+    reports.clear()
+    rc = bench.launch_ranks(a, ["--gpus", "4"], environ={}, popen=Proc, clock=lambda: now[0], sleep=sleep,
+                            evidence=lambda r: (0, 0.0) if r == 1 else (int(now[0] // 10), 0.0), report=reports.append)
+    assert rc == 124 and 60 < now[0] < 90 and len(reports) == 1
+    reports[:] = reports[:1]
 
     # a slow but living run is left alone; --rank-timeout 0 switches the watchdog off
     Proc.procs.clear()
