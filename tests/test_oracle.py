@@ -80,6 +80,23 @@ def test_oracle_vs_numpy_model_random(seed):
                 assert flags[f] == flag          # early exit == full count vs max(1, clusters_needed)
 
 
+@pytest.mark.parametrize("vec", [1, 2, 4, 8, 40])
+def test_oracle_vs_numpy_model_on_run_structured_frames(vec):
+    """The frames the GPU's run-aggregated vote path is tested on (tests/run_frames.py: every cell's votes arrive as
+    runs of 1..130 same-cell records, totals one short of / at / above VECTORS_NEEDED): the C oracle and the
+    independent numpy model agree on flag AND centre count, so the checker itself is cross-checked on this input."""
+    from run_frames import run_frames
+    p = ob.params_from_config(1920, 1080, vectors_needed=vec, clusters_needed=2, mv_threshold_sq=4.0)
+    rng = np.random.RandomState(500 + vec)
+    frames = run_frames(rng, 1920, 1080, 4, vec, 24, 3)
+    yes = 0
+    for fr in frames:
+        flag, centres, _ = ob.check_frame(p, fr, True, count_centres=True)
+        assert (flag, centres) == check_frame_np(p, fr, True)
+        yes += flag
+    assert 0 < yes < len(frames)
+
+
 def test_oracle_rejects_negative_margin():
     """vertical_margin < 0 would index before the grid in the reference (:237, :285): the oracle
     refuses it, like the product's validate_params."""
