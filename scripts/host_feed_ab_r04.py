@@ -45,6 +45,11 @@ SETS = {
         "4 MiB batches": {"MTGPU_BATCH_MB": "4"},
         "2 MiB batches": {"MTGPU_BATCH_MB": "2"},
     },
+    "batch2": {
+        "16 MiB batches": {"MTGPU_BATCH_MB": "16"},
+        "8 MiB batches": {"MTGPU_BATCH_MB": "8"},
+        "12 MiB batches": {"MTGPU_BATCH_MB": "12"},
+    },
 }
 SETTINGS = SETS[os.environ.get("SET", "final")]
 only = os.environ.get("ONLY")
