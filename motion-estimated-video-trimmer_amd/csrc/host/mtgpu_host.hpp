@@ -28,6 +28,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
 #include <memory>
 #include <mutex>
 #include <queue>
@@ -101,9 +102,12 @@ struct Config {   // same variables, defaults and parse types as config.hpp:56-1
 };
 
 // ---------------------------------------------------------------- CPU budget
-// CPUs' worth of run time this process may use — the order of the reference's detect_cpu_limit()
-// (src/system.cpp:107-164): cgroup v2 cpu.max, cgroup v1 cfs quota, cpuset, hardware_concurrency.
-inline int cpu_limit() {
+// CPUs' worth of run TIME the scheduler grants this process: the cgroup quota (v2 cpu.max, v1 cfs quota), rounded
+// up; without a quota the CPUs it may run on.  This is what the CpuGate below is sized from.  It is deliberately NOT
+// the reference's detect_cpu_limit() (reference_cpu_limit() further down): that function takes the LARGER of the
+// quota and the cpuset's CPU count (src/system.cpp:155-161) — on a box that shows 256 CPUs to a job with a 16-CPU
+// quota it answers 256, and 256 runnable workers are exactly what the quota throttles.
+inline int cpu_budget() {
   auto read_two = [](const char *path, long &a, long &b) {
     FILE *f = std::fopen(path, "r");
     if (!f) return false;
@@ -129,6 +133,107 @@ inline int cpu_limit() {
   return hc ? (int)hc : 1;
 }
 
+// ---- the reference's own sizing of streams and threads, restated (src/system.cpp:38-197, src/batch_processor.cpp:81-95)
+// and checked against the reference's object code where that builds (oracle/_ref/ref_host_probe `sizing`,
+// tests/test_reference_host.py).  `mtgpu_scan_file --streams 0 --threads 0` sizes a batch run with these, as
+// `motion_trim in_dir out_dir` does; an explicit stream count may exceed the CPUs (that is what the gate is for).
+namespace refsizing {
+inline long read_long_from_file(const char *path) {            // system.cpp:38-46 (a value without a newline after it is -1)
+  std::ifstream f(path);
+  if (!f) return -1;
+  long val;
+  f >> val;
+  return f.good() ? val : -1;
+}
+inline std::vector<int> parse_cpuset_string(const std::string &line) {   // system.cpp:49-80: "0,2,4" / "0-3"
+  std::vector<int> cpus;
+  size_t pos = 0;
+  while (pos < line.size()) {
+    size_t end = line.find_first_of(",-", pos);
+    if (end == std::string::npos) end = line.size();
+    const int start_cpu = std::stoi(line.substr(pos, end - pos));
+    if (end < line.size() && line[end] == '-') {
+      pos = end + 1;
+      end = line.find(',', pos);
+      if (end == std::string::npos) end = line.size();
+      const int end_cpu = std::stoi(line.substr(pos, end - pos));
+      for (int cpu = start_cpu; cpu <= end_cpu; ++cpu) cpus.push_back(cpu);
+    } else {
+      cpus.push_back(start_cpu);
+    }
+    pos = (end < line.size()) ? end + 1 : line.size();
+  }
+  return cpus;
+}
+inline std::vector<int> read_cpuset_file(const char *path) {   // system.cpp:94-101
+  std::ifstream f(path);
+  if (!f) return {};
+  std::string line;
+  std::getline(f, line);
+  return parse_cpuset_string(line);
+}
+inline int count_cpuset(const char *path) {                    // system.cpp:83-91
+  const std::vector<int> cpus = read_cpuset_file(path);
+  return cpus.empty() ? -1 : (int)cpus.size();
+}
+}  // namespace refsizing
+
+inline int reference_cpu_limit() {                             // detect_cpu_limit(), system.cpp:107-164
+  int limit = -1;
+  {
+    std::ifstream f("/sys/fs/cgroup/cpu.max");
+    if (f) {
+      std::string quota_str, period_str;
+      f >> quota_str >> period_str;
+      if (quota_str != "max" && !period_str.empty()) {
+        const long quota = std::stol(quota_str), period = std::stol(period_str);
+        if (quota > 0 && period > 0) limit = (int)((quota + period - 1) / period);
+      }
+    }
+  }
+  if (limit <= 0) {
+    const long quota = refsizing::read_long_from_file("/sys/fs/cgroup/cpu/cpu.cfs_quota_us");
+    const long period = refsizing::read_long_from_file("/sys/fs/cgroup/cpu/cpu.cfs_period_us");
+    if (quota > 0 && period > 0) limit = (int)((quota + period - 1) / period);
+  }
+  if (limit <= 0) {
+    limit = refsizing::count_cpuset("/sys/fs/cgroup/cpuset.cpus.effective");
+    if (limit <= 0) limit = refsizing::count_cpuset("/sys/fs/cgroup/cpuset/cpuset.cpus");
+  }
+  if (limit <= 0) limit = (int)std::thread::hardware_concurrency();
+  if (limit <= 0) limit = 4;                                   // :149-152 sanity checks
+  if (limit > 64) limit = 64;
+  int cpuset_count = refsizing::count_cpuset("/sys/fs/cgroup/cpuset.cpus.effective");   // :155-161 the larger of the two
+  if (cpuset_count <= 0) cpuset_count = refsizing::count_cpuset("/sys/fs/cgroup/cpuset/cpuset.cpus");
+  if (cpuset_count > limit) limit = cpuset_count;
+  return limit;
+}
+
+inline std::vector<int> reference_available_cpus() {           // get_available_cpus(), system.cpp:166-184
+  std::vector<int> cpus = refsizing::read_cpuset_file("/sys/fs/cgroup/cpuset.cpus.effective");
+  if (cpus.empty()) cpus = refsizing::read_cpuset_file("/sys/fs/cgroup/cpuset/cpuset.cpus");
+  if (cpus.empty()) {
+    const int limit = reference_cpu_limit();
+    for (int i = 0; i < limit; ++i) cpus.push_back(i);
+  }
+  return cpus;
+}
+
+inline int reference_parallel_streams() {                      // calculate_parallel_streams(), system.cpp:186-197
+  const int available = reference_cpu_limit();
+  const int configured = Config::parallel_streams();
+  if (configured == 0) return std::max(1, available);
+  return std::max(1, std::min(configured, available));
+}
+
+// BatchProcessor::process, batch_processor.cpp:81-95: streams capped at the available CPUs; THREADS_PER_STREAM, or
+// when that is 0 (auto) the available CPUs divided by the streams
+inline void reference_batch_sizing(int num_streams, int available_cpus, int configured_threads, int &streams, int &threads) {
+  streams = std::max(1, std::min(num_streams, available_cpus));
+  threads = configured_threads;
+  if (threads <= 0) threads = std::max(1, available_cpus / streams);
+}
+
 // At most `tokens` workers of the process FILL a staging batch (decode + copy-out) at any time; waiting for the GPU
 // holds no token.  The reference never runs more stream threads than CPUs (calculate_parallel_streams,
 // src/system.cpp:186-197: min(configured, detect_cpu_limit())); with GPUs in place of CPU sets the number of open
@@ -136,7 +241,7 @@ inline int cpu_limit() {
 // workers under a 16-CPU cgroup quota were each scheduled ~16 % of the time while "copying" (the quota is handed
 // to CPUs in slices; round 4, profiles/r04_host_feed_*.json), i.e. a copy-out that streams 37 GB/s per thread
 // when it runs delivered 2.7 GB/s per worker.  The gate keeps the runnable set at the CPU budget.
-// MTGPU_CPU_TOKENS: 0 = no gate, N = that many tokens, unset = 3/4 of cpu_limit() (rounded up): the budget also has to
+// MTGPU_CPU_TOKENS: 0 = no gate, N = that many tokens, unset = 3/4 of cpu_budget() (rounded up): the budget also has to
 // carry the HIP runtime's own threads and the wake-ups of the waiting workers — measured on a 16-CPU quota with 64
 // workers (profiles/r04_host_feed_ab_gate.json): no gate 84-99 k frames/s, 24 tokens 102 k, 16 tokens 115 k,
 // 12 tokens 135 k, 8 tokens 134 k.
@@ -150,7 +255,7 @@ class CpuGate {
   static CpuGate &instance() {
     static CpuGate g([] {
       const char *e = std::getenv("MTGPU_CPU_TOKENS");
-      return e ? std::max(0, std::atoi(e)) : std::max(1, (3 * cpu_limit() + 3) / 4);
+      return e ? std::max(0, std::atoi(e)) : std::max(1, (3 * cpu_budget() + 3) / 4);
     }());
     return g;
   }

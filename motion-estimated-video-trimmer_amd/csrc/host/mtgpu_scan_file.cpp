@@ -1,6 +1,7 @@
 // mtgpu_scan_file — the scan + merge half of `motion_trim` on the GPU, reading extracted motion
 // vectors from .mtmv containers instead of decoding with FFmpeg:
 //   mtgpu_scan_file stream.mtmv [more.mtmv ...] [--threads T] [--streams S] [--outdir DIR] [--timestamps] [--summary]
+//   (--streams 0 / --threads 0: the reference's own sizing from PARALLEL_STREAMS / THREADS_PER_STREAM and the CPU limit)
 // One file: like `motion_trim in out` (single ProcessingPipeline).  Several files: like
 // `motion_trim in_dir out_dir` (BatchProcessor): S streams x T workers, jobs consumed by one
 // thread (here: printed).  Configuration comes from the same environment variables as the
@@ -98,6 +99,20 @@ int main(int argc, char **argv) {
     else if (!std::strcmp(argv[i], "--summary")) g_summary = true;
     else if (!std::strcmp(argv[i], "--repeat") && i + 1 < argc) repeat = std::atol(argv[++i]);
     else files.push_back(argv[i]);
+  }
+  // --streams 0 / --threads 0: sized as the reference sizes a batch run (calculate_parallel_streams() streams,
+  // src/system.cpp:186-197; THREADS_PER_STREAM or CPUs / streams threads, src/batch_processor.cpp:81-95)
+  if (streams <= 0 || threads <= 0) {
+    try {
+      const int avail = (int)reference_available_cpus().size();
+      int st = streams > 0 ? streams : reference_parallel_streams(), th = 0;
+      reference_batch_sizing(st, avail, threads > 0 ? threads : Config::threads_per_stream(), st, th);
+      if (streams <= 0) streams = st;
+      if (threads <= 0) threads = th;
+    } catch (const std::exception &e) {
+      std::fprintf(stderr, "error: configuration: %s\n", e.what());
+      return 1;
+    }
   }
   if (files.empty()) {
     std::fprintf(stderr, "usage: %s stream.mtmv [more.mtmv ...] [--threads T] [--streams S] [--outdir DIR]\n", argv[0]);

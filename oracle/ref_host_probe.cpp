@@ -14,6 +14,10 @@
 //   ref_host_probe layout            -> sizeof / alignof / offsets of TimeSegment, ScanTask
 //   ref_host_probe queue  < script   -> TaskQueue / ResultCollector / FFmpegQueue driven by a script
 //   ref_host_probe race N T          -> T threads drain N tasks; prints how often each id was popped
+//   ref_host_probe sizing            -> detect_cpu_limit(), calculate_parallel_streams(), get_available_cpus() of
+//                                       src/system.cpp on THIS machine (only when the recipe could build system.cpp:
+//                                       it needs <fmt/core.h>, taken from the fmt headers the image ships inside
+//                                       PyTorch — the real library, header-only mode, not a stand-in)
 #include <cstddef>
 #include <cstdio>
 #include <cstdlib>
@@ -32,7 +36,28 @@
 #include "motion_trim/task_queue.hpp"
 #include "motion_trim/types.hpp"
 
+#ifdef MT_REF_HAVE_SYSTEM
+#include "motion_trim/system.hpp"
+#endif
+
 namespace mt = motion_trim;
+
+static int cmd_sizing() {
+#ifdef MT_REF_HAVE_SYSTEM
+  std::printf("detect_cpu_limit %d\n", mt::detect_cpu_limit());
+  try {
+    std::printf("calculate_parallel_streams %d\n", mt::calculate_parallel_streams());
+  } catch (const std::exception &e) {
+    std::printf("calculate_parallel_streams throws %s\n", typeid(e).name());
+  }
+  const std::vector<int> cpus = mt::get_available_cpus();
+  std::printf("available_cpus %zu first %d last %d\n", cpus.size(), cpus.empty() ? -1 : cpus.front(), cpus.empty() ? -1 : cpus.back());
+  return 0;
+#else
+  std::printf("unavailable\n");
+  return 0;
+#endif
+}
 
 template <class F> static void show_d(const char *name, F f) {
   try {
@@ -232,6 +257,7 @@ static int cmd_race(int n, int threads) {
 
 int main(int argc, char **argv) {
   const std::string cmd = argc > 1 ? argv[1] : "";
+  if (cmd == "sizing") return cmd_sizing();
   if (cmd == "config") return cmd_config();
   if (cmd == "memo") return cmd_memo();
   if (cmd == "layout") return cmd_layout();

@@ -12,6 +12,7 @@
 #include <stdexcept>
 #include <string>
 #include <thread>
+#include <typeinfo>
 #include <vector>
 
 #include "mtgpu_host.hpp"
@@ -225,7 +226,7 @@ static int cmd_concat(const char *path) {
 }
 
 // gate N T R: T threads pass R times through a CpuGate of N tokens; prints the highest number of threads ever
-// inside at once, the passes made and whether anybody had to wait; `cpulimit` prints cpu_limit()
+// inside at once, the passes made and whether anybody had to wait; `cpulimit` prints cpu_budget()
 static int cmd_gate(int tokens, int threads, int rounds) {
   h::CpuGate gate(tokens);
   std::atomic<int> inside{0}, peak{0}, passes{0};
@@ -251,7 +252,24 @@ static int cmd_gate(int tokens, int threads, int rounds) {
 int main(int argc, char **argv) {
   const std::string cmd = argc > 1 ? argv[1] : "";
   if (cmd == "gate" && argc == 5) return cmd_gate(std::atoi(argv[2]), std::atoi(argv[3]), std::atoi(argv[4]));
-  if (cmd == "cpulimit") { std::printf("%d\n", h::cpu_limit()); return 0; }
+  if (cmd == "cpulimit") { std::printf("%d\n", h::cpu_budget()); return 0; }
+  if (cmd == "sizing") {      // the same three lines oracle/_ref/ref_host_probe `sizing` prints from the reference's system.cpp
+    std::printf("detect_cpu_limit %d\n", h::reference_cpu_limit());
+    try {
+      std::printf("calculate_parallel_streams %d\n", h::reference_parallel_streams());
+    } catch (const std::exception &e) {
+      std::printf("calculate_parallel_streams throws %s\n", typeid(e).name());
+    }
+    const std::vector<int> cpus = h::reference_available_cpus();
+    std::printf("available_cpus %zu first %d last %d\n", cpus.size(), cpus.empty() ? -1 : cpus.front(), cpus.empty() ? -1 : cpus.back());
+    return 0;
+  }
+  if (cmd == "batchsizing" && argc == 5) {   // num_streams available_cpus configured_threads -> streams threads
+    int st = 0, th = 0;
+    h::reference_batch_sizing(std::atoi(argv[2]), std::atoi(argv[3]), std::atoi(argv[4]), st, th);
+    std::printf("%d %d\n", st, th);
+    return 0;
+  }
   if (cmd == "concat" && argc == 4 && std::string(argv[3]) == "--setlocale") {
     std::setlocale(LC_ALL, "");          // adopt LC_ALL from the environment, as a host application might
     return cmd_concat(argv[2]);

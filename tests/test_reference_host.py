@@ -332,10 +332,43 @@ def test_concat_list_text(host_probe):
         assert out == want_big, loc
 
 
-def test_cpu_gate_and_cpu_limit(host_probe):
-    """The host layer's CPU budget: cpu_limit() follows the reference's detect_cpu_limit() order
-    (src/system.cpp:107-164: cgroup v2 cpu.max, cgroup v1 quota, cpuset, hardware threads — rounded up), and the
-    CpuGate never lets more workers fill batches at once than it has tokens (0 tokens = no gate)."""
+def _ref_has_sizing():
+    if not os.path.exists(REF_PROBE):
+        return False
+    try:
+        return subprocess.run([REF_PROBE, "sizing"], capture_output=True, text=True).stdout.strip() not in ("", "unavailable")
+    except OSError:
+        return False
+
+
+@pytest.mark.skipif(not _ref_has_sizing(), reason="oracle/_ref/ref_host_probe was built without the reference's system.cpp")
+def test_stream_sizing_matches_the_references_system_cpp_on_this_machine(host_probe):
+    """Row a11 (stream fan-out): how many streams the reference starts — detect_cpu_limit(), get_available_cpus() and
+    calculate_parallel_streams() (src/system.cpp:107-197) — restated in the host layer (reference_cpu_limit /
+    reference_available_cpus / reference_parallel_streams) and compared here, line for line, with the reference's OWN
+    object code (src/system.cpp compiled where it lies into oracle/_ref/ref_host_probe) on this machine's real cgroup
+    files, for PARALLEL_STREAMS unset / 0 / 3 / 64 / 100000 / -2 / unparsable (std::stoi throws in both)."""
+    for ps in (None, "0", "3", "64", "100000", "-2", "abc", "7xyz"):
+        env = {} if ps is None else {"PARALLEL_STREAMS": ps}
+        ref = run(REF_PROBE, ["sizing"], env)
+        assert len(ref) == 3 and ref[0].startswith("detect_cpu_limit ")
+        assert run(host_probe, ["sizing"], env) == ref, ps
+
+
+def test_batch_sizing_hand_cases(host_probe):
+    """BatchProcessor::process, src/batch_processor.cpp:81-95 (that file needs libav and cannot be built: hand-derived):
+    streams = max(1, min(num_streams, available CPUs)); threads = THREADS_PER_STREAM, or available / streams when 0."""
+    cases = [((3, 8, 0), (3, 2)), ((64, 16, 0), (16, 1)), ((2, 16, 0), (2, 8)), ((5, 16, 0), (5, 3)), ((0, 8, 0), (1, 8)),
+             ((-3, 8, 0), (1, 8)), ((3, 8, 4), (3, 4)), ((64, 16, 4), (16, 4)), ((3, 2, 0), (2, 1)), ((3, 8, -1), (3, 2))]
+    for (ns, av, th), want in cases:
+        assert tuple(int(x) for x in run(host_probe, ["batchsizing", str(ns), str(av), str(th)])[0].split()) == want, (ns, av, th)
+
+
+def test_cpu_gate_and_cpu_budget(host_probe):
+    """The host layer's CPU budget for the gate: cpu_budget() = the cgroup QUOTA (v2 cpu.max, v1 cfs quota, rounded
+    up), else the CPUs the process may run on — deliberately not the reference's detect_cpu_limit(), which takes the
+    larger of quota and cpuset size (see test_stream_sizing_...) — and the CpuGate never lets more workers fill
+    batches at once than it has tokens (0 tokens = no gate)."""
     def want_limit():
         try:
             q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
