@@ -30,7 +30,6 @@ def run_frames(rng, width, height, shift, vec, n_frames, margin_rows, totals=Non
         for i in order:
             cx, cy, n = runs[i]
             k = int(rng.choice([0, 0, 1, 2, 3, 5, 17, 60, 64, 200]))
-            recs += [(int(rng.randint(0, width)), int(rng.randint(0, height)), 0)] * 0
             fx, fy = rng.randint(0, width, size=k), rng.randint(0, height, size=k)
             recs += [(int(a), int(b), 0) for a, b in zip(fx, fy)]
             x = (cx << shift) + rng.randint(0, 1 << shift, size=n)
