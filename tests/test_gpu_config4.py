@@ -201,3 +201,20 @@ def test_multi_device_paths_of_the_host_layer_on_aliased_devices(streams64):
     r1, jobs1, s1 = _run(some, 8, 2, d)
     assert s1["held"]["contexts"] == 1
     assert sorted(json.dumps(j["segments"]) + j["input"] for j in jobs) == sorted(json.dumps(j["segments"]) + j["input"] for j in jobs1)
+
+
+def test_batch_sized_like_the_reference_when_no_counts_are_given(streams64):
+    """`mtgpu_scan_file --streams 0 --threads 0` sizes the batch as `motion_trim in_dir out_dir` does: PARALLEL_STREAMS
+    capped by the reference's CPU limit (calculate_parallel_streams, src/system.cpp:186-197), THREADS_PER_STREAM
+    (src/batch_processor.cpp:81-95) — restated in the host layer and checked against the reference's own system.cpp in
+    tests/test_reference_host.py; here: the front end really uses it, and the jobs stay bit-exact."""
+    d, paths, cases = streams64
+    some = paths[:8]
+    r, jobs, s = _run(some, 0, 0, d, {"PARALLEL_STREAMS": "4", "THREADS_PER_STREAM": "2"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert (s["streams"], s["threads_per_stream"]) == (4, 2)
+    _check_all(jobs, cases, some)
+    exe = os.path.join(os.path.dirname(m.LIB_PATH), "mtgpu_scan_file")
+    r = subprocess.run([exe] + some + ["--streams", "0", "--threads", "0", "--outdir", d], capture_output=True, text=True,
+                       env=dict(os.environ, PARALLEL_STREAMS="abc"), timeout=120)
+    assert r.returncode == 1 and "configuration" in r.stderr and r.stdout == ""
