@@ -426,6 +426,8 @@ def host_fed_batch64(exe, n=12, reps=600, extra_env=None, configs=((64, 1), (16,
                 # well below 1 = workers were runnable but not running (more runnable threads than the CPU budget)
                 "worker_cpu_over_copy_submit_wall": s.get("worker_cpu_us", 0) / max(s["copy_us"] + s["submit_us"], 1),
                 "cpu_gate": {"tokens": s.get("gate_tokens", 0), "wait_share_of_worker_time": s.get("gate_wait_us", 0) / (workers * wall * 1e6)},
+                # CPUs next to the device that the worker threads are confined to (0 = not pinned: no CPU quota in force)
+                "cpu_window": {"cpus": s.get("cpu_window", 0), "first": s.get("cpu_window_first", -1)},
                 "setup_ms": {"mtgpu_create_total": s["held"].get("ctx_create_us", 0) / 1e3,
                              "mtgpu_pipe_create_per_worker": s["held"].get("pipe_create_us", 0) / 1e3 / max(workers, 1),
                              # page-locking incl. the batches pinned later, on first use (summed over the run / per worker)

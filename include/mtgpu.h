@@ -45,6 +45,12 @@ const char *mtgpu_last_error(void);
  * get_available_cpus() for the stream->GPU assignment (src/system.cpp:166-184). */
 int mtgpu_device_count(void);
 
+/* PCI address of a device as "dddd:bb:dd.f" (lower case) into buf — what /sys/bus/pci/devices/<address>/ is named
+ * after, where `local_cpulist` and `numa_node` say which CPUs sit next to the GPU.  The host layer places its
+ * worker threads there (the reference pins its stream threads to CPU sets: src/batch_processor.cpp:102-110,
+ * src/system.cpp:199-225).  MT_ERR_CAPACITY if cap < 13. */
+int mtgpu_device_pci_address(int device, char *buf, uint64_t cap);
+
 /*
  * Derive the parameter block exactly as MotionScanner::initialize() does
  * (src/motion_scanner.cpp:184-199; defaults include/motion_trim/config.hpp:56-89):

@@ -80,6 +80,7 @@ ABI = {
     "mtgpu_version": (C.c_char_p, []),
     "mtgpu_last_error": (C.c_char_p, []),
     "mtgpu_device_count": (C.c_int, []),
+    "mtgpu_device_pci_address": (C.c_int, [C.c_int, C.c_char_p, C.c_uint64]),
     "mtgpu_params_from_config": (C.c_int, [C.POINTER(ScanParamsC), C.c_int, C.c_int, C.c_double,
                                            C.c_int, C.c_int, C.c_int, C.c_int, C.c_float]),
     "mtgpu_create": (C.c_int, [C.POINTER(ScanParamsC), C.c_int, C.POINTER(C.c_void_p)]),

@@ -37,7 +37,9 @@
 #include <thread>
 #include <vector>
 
+#include <dirent.h>
 #include <fcntl.h>
+#include <pthread.h>
 #include <sched.h>
 #include <sys/mman.h>
 #include <sys/resource.h>
@@ -232,6 +234,119 @@ inline void reference_batch_sizing(int num_streams, int available_cpus, int conf
   streams = std::max(1, std::min(num_streams, available_cpus));
   threads = configured_threads;
   if (threads <= 0) threads = std::max(1, available_cpus / streams);
+}
+
+// ---------------------------------------------------------------- where the worker threads run
+// The reference pins every stream thread to its own CPU set (src/batch_processor.cpp:102-110, pin_thread_to_cpus
+// src/system.cpp:211-225).  With GPUs in place of CPU sets the workers of a device share ONE window of CPUs next to
+// that device instead — and the window is sized from the CPU budget, for a measured reason: under a cgroup quota the
+// kernel hands run time to CPUs in slices, so 64 workers that wake up on 64 different CPUs of a 256-CPU box drain a
+// 16-CPU quota in bursts and the whole group is throttled for the rest of the period (28 of 40 periods), while the
+// GPU — its submitters descheduled — sat idle 41 % of the time (profiles/r04_host_feed_kernel_view.txt).  Confined to
+// 24 CPUs the same run scanned 171-174 k frames/s instead of 141-145 k; to 16 CPUs 120 k (too few to also run the
+// runtime's own threads), to 32 CPUs 155-159 k (profiles/r04_host_feed_cpu_window.txt).
+//
+// pick_cpu_window: pure arithmetic (tested on the CPU tier).  `local` = the CPUs next to the device in sysfs order
+// (e.g. "64-127,192-255": a socket's cores, then their SMT siblings), `gpu_index` of `gpus_on_node` GPUs share
+// them: the cores are cut into equal parts, part gpu_index is ours, and the window is its first `want` CPUs — cores
+// first, then the siblings of the same cores.  Every GPU of a node gets a disjoint window.
+inline std::vector<int> pick_cpu_window(const std::vector<int> &local, int gpu_index, int gpus_on_node, int want) {
+  std::vector<int> out;
+  if (local.empty() || want <= 0) return out;
+  gpus_on_node = std::max(1, gpus_on_node);
+  gpu_index = std::min(std::max(0, gpu_index), gpus_on_node - 1);
+  // contiguous ranges of the list, in order
+  std::vector<std::pair<size_t, size_t>> ranges;          // [begin, end) into `local`
+  size_t b = 0;
+  for (size_t i = 1; i <= local.size(); ++i)
+    if (i == local.size() || local[i] != local[i - 1] + 1) { ranges.push_back({b, i}); b = i; }
+  const size_t first_len = ranges[0].second - ranges[0].first;
+  // "cores, then their SMT siblings": exactly two equally long ranges (a node's sysfs local_cpulist, "64-127,192-255")
+  const bool smt_layout = ranges.size() == 2 && first_len >= 2 && ranges[1].second - ranges[1].first == first_len;
+  const size_t pool_len = smt_layout ? first_len : local.size();          // the "cores" that get partitioned
+  const size_t per = std::max<size_t>(1, pool_len / (size_t)gpus_on_node);
+  const size_t lo = std::min(pool_len, per * (size_t)gpu_index), hi = std::min(pool_len, lo + per);
+  for (size_t i = lo; i < hi && (int)out.size() < want; ++i) out.push_back(local[i]);
+  if (smt_layout)
+    for (size_t r = 1; r < ranges.size() && (int)out.size() < want; ++r)
+      if (ranges[r].second - ranges[r].first == first_len)
+        for (size_t i = lo; i < hi && (int)out.size() < want; ++i) out.push_back(local[ranges[r].first + i]);
+  return out;
+}
+
+// The window for the workers of `device`, or empty = do not pin.  MTGPU_CPU_WINDOW: "off" / "0" = never pin;
+// a number = that many CPUs; a cpulist ("64-87") = exactly those; unset = ceil(1.5 x cpu_budget()) CPUs, and only when
+// the budget is a real restriction (fewer CPUs' worth of time than CPUs the process may run on).
+inline std::vector<int> cpu_window_for_device(int device) {
+  static std::mutex mu;
+  static std::vector<std::pair<int, std::vector<int>>> cache;
+  std::lock_guard<std::mutex> l(mu);
+  for (auto &c : cache) if (c.first == device) return c.second;
+  std::vector<int> win;
+  try {
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    std::vector<int> allowed;
+    if (sched_getaffinity(0, sizeof set, &set) == 0)
+      for (int c = 0; c < CPU_SETSIZE; ++c) if (CPU_ISSET(c, &set)) allowed.push_back(c);
+    const char *e = std::getenv("MTGPU_CPU_WINDOW");
+    const std::string env = e ? e : "";
+    int want = 0;
+    if (env == "off" || env == "0") want = 0;
+    else if (!env.empty() && env.find_first_of(",-") != std::string::npos) {
+      for (int c : refsizing::parse_cpuset_string(env)) if (std::find(allowed.begin(), allowed.end(), c) != allowed.end()) win.push_back(c);
+      cache.push_back({device, win});
+      return win;
+    } else if (!env.empty()) want = std::max(0, std::atoi(env.c_str()));
+    else {
+      const int budget = cpu_budget();
+      want = budget < (int)allowed.size() ? (3 * budget + 1) / 2 : 0;
+    }
+    if (want > 0 && want < (int)allowed.size()) {
+      std::vector<int> local = allowed;
+      int gpu_index = 0, gpus_on_node = 1;
+      char addr[32] = "";
+      if (mtgpu_device_pci_address(device, addr, sizeof addr) == MT_OK) {
+        const std::string dir = std::string("/sys/bus/pci/devices/") + addr;
+        std::vector<int> near;
+        for (int c : refsizing::read_cpuset_file((dir + "/local_cpulist").c_str()))
+          if (std::find(allowed.begin(), allowed.end(), c) != allowed.end()) near.push_back(c);
+        if ((int)near.size() >= want) {
+          local = near;
+          // the GPUs that share these CPUs: AMD devices of the same class on the same NUMA node, in address order
+          auto slurp = [](const std::string &p) { std::ifstream f(p); std::string t; if (f) std::getline(f, t); return t; };
+          const std::string my_node = slurp(dir + "/numa_node"), my_class = slurp(dir + "/class");
+          std::vector<std::string> peers;
+          if (DIR *d = opendir("/sys/bus/pci/devices")) {
+            while (dirent *de = readdir(d)) {
+              const std::string n = de->d_name;
+              if (n.size() < 12) continue;
+              const std::string pd = "/sys/bus/pci/devices/" + n;
+              if (slurp(pd + "/vendor") == "0x1002" && slurp(pd + "/class") == my_class && slurp(pd + "/numa_node") == my_node) peers.push_back(n);
+            }
+            closedir(d);
+          }
+          std::sort(peers.begin(), peers.end());
+          const auto it = std::find(peers.begin(), peers.end(), std::string(addr));
+          if (it != peers.end()) { gpu_index = (int)(it - peers.begin()); gpus_on_node = (int)peers.size(); }
+        }
+      }
+      win = pick_cpu_window(local, gpu_index, gpus_on_node, want);
+      if ((int)win.size() < std::min(want, 2)) win.clear();
+    }
+  } catch (...) {
+    win.clear();                      // an unreadable / malformed sysfs entry: no pinning
+  }
+  cache.push_back({device, win});
+  return win;
+}
+
+inline bool pin_this_thread(const std::vector<int> &cpus) {    // pin_thread_to_cpus, src/system.cpp:211-225
+  if (cpus.empty()) return false;
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  for (int c : cpus) if (c >= 0 && c < CPU_SETSIZE) CPU_SET(c, &set);
+  return pthread_setaffinity_np(pthread_self(), sizeof set, &set) == 0;
 }
 
 // At most `tokens` workers of the process FILL a staging batch (decode + copy-out) at any time; waiting for the GPU
@@ -806,9 +921,11 @@ int run_scan_pipeline(MakeSource make_source, int num_threads, PipelineResult &o
       };
       try {
         const auto i0 = std::chrono::high_resolution_clock::now();
+        const int dev = worker_device(device_base, i, n_dev);
+        (void)pin_this_thread(cpu_window_for_device(dev));               // :192-194 (optional pinning), next to the device
         sources[i] = make_source();
         GpuBackend *shared = (pool && (size_t)i < pool->size()) ? (*pool)[i].get() : nullptr;
-        scanners[i] = std::make_unique<GpuMotionScanner>(*sources[i], worker_device(device_base, i, n_dev), shared);
+        scanners[i] = std::make_unique<GpuMotionScanner>(*sources[i], dev, shared);
         if (!scanners[i]->initialize()) {                                // :198-199 (here: reported)
           fail_with(scanners[i]->error());
           return;
@@ -942,6 +1059,7 @@ struct BatchSummary {   // what a whole process_batch run did and what it held (
   long init_us = 0, decode_us = 0, analyze_us = 0, copy_us = 0, submit_us = 0, wait_us = 0;   // summed over all workers
   long worker_cpu_us = 0;                                  // CPU time the worker threads got (thread clocks, summed)
   long gate_wait_us = 0; int gate_tokens = 0;              // CpuGate: time workers waited for a CPU token / tokens
+  int cpu_window = 0, cpu_window_first = -1;               // CPUs the workers of device 0 are confined to (0 = not pinned) / the first of them
   long cpu_user_us = 0, cpu_sys_us = 0;                    // CPU time the whole process spent during the run (getrusage):
                                                            // (user + sys) / wall = CPUs kept busy, against the box's quota
   Resources held;                                          // summed over the S x T backends alive at the end
@@ -968,6 +1086,10 @@ int process_batch(const std::vector<std::string> &files, const std::string &outp
   std::vector<std::thread> streams;
   for (int s = 0; s < parallel_streams; ++s) {
     streams.emplace_back([&, s] {
+      {   // the stream thread itself (probe, chunking, merge call) sits with its first worker (batch_processor.cpp:311-322)
+        const int nd = mtgpu_device_count();
+        if (nd > 0) (void)pin_this_thread(cpu_window_for_device(worker_device(s * threads_per_stream, 0, nd)));
+      }
       // this stream's workers keep their GPU contexts + pinned pipes from one video to the next
       std::vector<std::unique_ptr<GpuBackend>> pool;
       for (int i = 0; i < threads_per_stream; ++i) pool.emplace_back(new GpuBackend());
@@ -1051,6 +1173,11 @@ int process_batch(const std::vector<std::string> &files, const std::string &outp
     sum.cpu_sys_us = us(ru0.ru_stime, ru1.ru_stime);
     sum.gate_wait_us = (long)(CpuGate::instance().wait_us() - gate_wait0);
     sum.gate_tokens = CpuGate::instance().tokens();
+    if (mtgpu_device_count() > 0) {
+      const std::vector<int> w = cpu_window_for_device(0);
+      sum.cpu_window = (int)w.size();
+      sum.cpu_window_first = w.empty() ? -1 : w.front();
+    }
   }
   if (summary) *summary = sum;
   return failed.load();

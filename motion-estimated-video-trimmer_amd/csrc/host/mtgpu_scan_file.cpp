@@ -153,13 +153,13 @@ int main(int argc, char **argv) {
       const Resources &h = sum.held;
       std::printf("{\"batch_summary\": {\"streams\": %d, \"threads_per_stream\": %d, \"videos\": %zu, \"jobs\": %zu, "
                   "\"failed\": %zu, \"frames_scanned\": %llu, \"wall_us\": %ld, \"scan_wall_us\": %ld, \"scan_window_us\": %ld, \"init_us\": %ld, \"decode_us\": %ld, "
-                  "\"analyze_us\": %ld, \"copy_us\": %ld, \"submit_us\": %ld, \"wait_us\": %ld, \"cpu_user_us\": %ld, \"cpu_sys_us\": %ld, \"worker_cpu_us\": %ld, \"gate_wait_us\": %ld, \"gate_tokens\": %d, "
+                  "\"analyze_us\": %ld, \"copy_us\": %ld, \"submit_us\": %ld, \"wait_us\": %ld, \"cpu_user_us\": %ld, \"cpu_sys_us\": %ld, \"worker_cpu_us\": %ld, \"gate_wait_us\": %ld, \"gate_tokens\": %d, \"cpu_window\": %d, \"cpu_window_first\": %d, "
                   "\"held\": {\"contexts\": %llu, \"pipes\": %llu, \"hip_streams\": %llu, \"hip_events\": %llu, "
                   "\"mem_pools\": %llu, \"pinned_bytes\": %llu, \"device_bytes\": %llu, \"scratch_pool_high_bytes\": %llu, "
                   "\"submits\": %llu, \"ctx_create_us\": %llu, \"pipe_create_us\": %llu, \"pipe_rebuilds\": %llu, \"pin_us\": %llu, \"pinned_batches\": %llu}}}\n",
                   sum.streams, sum.threads_per_stream, sum.videos, sum.jobs, sum.failed,
                   (unsigned long long)sum.frames_scanned, sum.wall_us, sum.scan_wall_us, sum.scan_window_us, sum.init_us, sum.decode_us, sum.analyze_us,
-                  sum.copy_us, sum.submit_us, sum.wait_us, sum.cpu_user_us, sum.cpu_sys_us, sum.worker_cpu_us, sum.gate_wait_us, sum.gate_tokens, (unsigned long long)h.contexts, (unsigned long long)h.pipes,
+                  sum.copy_us, sum.submit_us, sum.wait_us, sum.cpu_user_us, sum.cpu_sys_us, sum.worker_cpu_us, sum.gate_wait_us, sum.gate_tokens, sum.cpu_window, sum.cpu_window_first, (unsigned long long)h.contexts, (unsigned long long)h.pipes,
                   (unsigned long long)h.hip_streams, (unsigned long long)h.hip_events, (unsigned long long)h.mem_pools,
                   (unsigned long long)h.pinned_bytes, (unsigned long long)h.device_bytes,
                   (unsigned long long)h.pool_reserved_high, (unsigned long long)h.submits,

@@ -4,6 +4,7 @@
 // the CPU (no fallback: without a usable device every compute call fails).
 #include <hip/hip_runtime.h>
 
+#include <cctype>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -453,6 +454,22 @@ int mtgpu_device_count(void) {
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   if (n > 0 && alias_devices() > 0) return alias_devices();
   return n;
+}
+
+int mtgpu_device_pci_address(int device, char *buf, uint64_t cap) {
+  if (!buf) return fail(MT_ERR_INVALID, "buf is NULL");
+  if (cap < 13) return fail(MT_ERR_CAPACITY, "buffer too small for a PCI address (13 bytes)");
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n < 1) return fail(MT_ERR_DEVICE, "no HIP device available");
+  const int logical = alias_devices() > 0 ? alias_devices() : n;
+  if (device < 0 || device >= logical) return fail(MT_ERR_INVALID, "device %d outside [0,%d)", device, logical);
+  char tmp[64] = "";
+  hipError_t e = hipDeviceGetPCIBusId(tmp, (int)sizeof tmp, device % n);
+  if (e != hipSuccess) return hip_fail(e, "hipDeviceGetPCIBusId");
+  size_t i = 0;
+  for (; tmp[i] && i + 1 < cap; ++i) buf[i] = (char)std::tolower((unsigned char)tmp[i]);
+  buf[i] = 0;
+  return MT_OK;
 }
 
 int mtgpu_params_from_config(mt_scan_params *out, int width, int height, double mv_threshold_sq,

@@ -45,6 +45,19 @@ SETS = {
         "4 MiB batches": {"MTGPU_BATCH_MB": "4"},
         "2 MiB batches": {"MTGPU_BATCH_MB": "2"},
     },
+    # workers confined to a window of CPUs next to the device (MTGPU_CPU_WINDOW) x CPU tokens
+    "window": {
+        "no window (workers float over every CPU)": {"MTGPU_CPU_WINDOW": "off"},
+        "auto window (1.5 x the CPU budget)": {},
+        "window 16": {"MTGPU_CPU_WINDOW": "16"},
+        "window 20": {"MTGPU_CPU_WINDOW": "20"},
+        "window 28": {"MTGPU_CPU_WINDOW": "28"},
+        "window 32": {"MTGPU_CPU_WINDOW": "32"},
+        "auto window, 16 tokens": {"MTGPU_CPU_TOKENS": "16"},
+        "auto window, 8 tokens": {"MTGPU_CPU_TOKENS": "8"},
+        "auto window, no gate": {"MTGPU_CPU_TOKENS": "0"},
+        "window 32, 16 tokens": {"MTGPU_CPU_WINDOW": "32", "MTGPU_CPU_TOKENS": "16"},
+    },
     "batch2": {
         "16 MiB batches": {"MTGPU_BATCH_MB": "16"},
         "8 MiB batches": {"MTGPU_BATCH_MB": "8"},
@@ -72,7 +85,7 @@ for p in range(int(os.environ.get("PASSES", "2"))):
         throttle = {k: c1.get(k, 0) - c0.get(k, 0) for k in ("nr_periods", "nr_throttled", "throttled_usec")}
         keep = {k: {kk: vv for kk, vv in v.items() if kk in ("frames_per_s_wall", "frames_per_s_steady", "wall_ms", "setup_ms",
                                                              "worker_time_share", "cpus_busy", "error",
-                                                             "worker_cpu_over_copy_submit_wall", "cpu_gate")}
+                                                             "worker_cpu_over_copy_submit_wall", "cpu_gate", "cpu_window")}
                 for k, v in r.items() if isinstance(v, dict)}
         keep["cgroup_cpu_stat_delta_incl_file_generation"] = throttle
         out.setdefault(name, []).append(keep)

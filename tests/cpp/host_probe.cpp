@@ -264,6 +264,12 @@ int main(int argc, char **argv) {
     std::printf("available_cpus %zu first %d last %d\n", cpus.size(), cpus.empty() ? -1 : cpus.front(), cpus.empty() ? -1 : cpus.back());
     return 0;
   }
+  if (cmd == "window" && argc == 6) {        // local_cpulist gpu_index gpus_on_node want -> the window
+    const std::vector<int> w = h::pick_cpu_window(h::refsizing::parse_cpuset_string(argv[2]), std::atoi(argv[3]), std::atoi(argv[4]), std::atoi(argv[5]));
+    for (size_t i = 0; i < w.size(); ++i) std::printf("%s%d", i ? "," : "", w[i]);
+    std::printf("\n");
+    return 0;
+  }
   if (cmd == "batchsizing" && argc == 5) {   // num_streams available_cpus configured_threads -> streams threads
     int st = 0, th = 0;
     h::reference_batch_sizing(std::atoi(argv[2]), std::atoi(argv[3]), std::atoi(argv[4]), st, th);

@@ -391,3 +391,23 @@ def test_cpu_gate_and_cpu_budget(host_probe):
     assert passes == 80 and waited == 0 and tokens == 0 and 1 <= peak <= 8
     peak, passes, waited, tokens = (int(x) for x in run(host_probe, ["gate", "16", "4", "10"])[0].split()[1::2])
     assert peak <= 4 and passes == 40 and waited == 0
+
+
+def test_cpu_window_next_to_the_device(host_probe):
+    """pick_cpu_window (host layer): the workers of a device are confined to a window of CPUs next to it, sized from
+    the CPU budget; the GPUs of a NUMA node get disjoint windows — cores first, then the SMT siblings of the same
+    cores.  Hand cases on the GPU box's layout (node 1: "64-127,192-255", four GPUs) and on flat lists."""
+    def win(local, idx, n, want):
+        out = run(host_probe, ["window", local, str(idx), str(n), str(want)])[0]
+        return [int(x) for x in out.split(",")] if out else []
+    node1 = "64-127,192-255"
+    assert win(node1, 0, 4, 16) == list(range(64, 80))
+    assert win(node1, 3, 4, 16) == list(range(112, 128))
+    assert win(node1, 3, 4, 24) == list(range(112, 128)) + list(range(240, 248))       # 16 cores + 8 of their siblings
+    assert win(node1, 1, 4, 40) == list(range(80, 96)) + list(range(208, 224))         # no more than the part holds
+    ws = [set(win(node1, g, 4, 24)) for g in range(4)]
+    assert all(len(w) == 24 for w in ws) and not any(ws[a] & ws[b] for a in range(4) for b in range(a + 1, 4))
+    assert win("0-7", 0, 1, 6) == [0, 1, 2, 3, 4, 5] and win("0-7", 1, 2, 6) == [4, 5, 6, 7]
+    assert win("0,2,4,6,8,10,12,14", 1, 2, 3) == [8, 10, 12]                            # compose pins cpuset 0,2,...,14 in the reference
+    assert win("0-7", 5, 2, 2) == [4, 5] and win("0-7", -1, 2, 2) == [0, 1]             # index clamped
+    assert win("0-7", 0, 1, 0) == []
