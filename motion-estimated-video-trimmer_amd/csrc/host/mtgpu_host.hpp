@@ -242,14 +242,15 @@ inline void reference_batch_sizing(int num_streams, int available_cpus, int conf
 // that device instead — and the window is sized from the CPU budget, for a measured reason: under a cgroup quota the
 // kernel hands run time to CPUs in slices, so 64 workers that wake up on 64 different CPUs of a 256-CPU box drain a
 // 16-CPU quota in bursts and the whole group is throttled for the rest of the period (28 of 40 periods), while the
-// GPU — its submitters descheduled — sat idle 41 % of the time (profiles/r04_host_feed_kernel_view.txt).  Confined to
-// 24 CPUs the same run scanned 171-174 k frames/s instead of 141-145 k; to 16 CPUs 120 k (too few to also run the
-// runtime's own threads), to 32 CPUs 155-159 k (profiles/r04_host_feed_cpu_window.txt).
+// GPU — its submitters descheduled — sat idle 41 % of the time (profiles/r04_host_feed_kernel_view.txt).  A first
+// trial with `taskset` (profiles/r04_host_feed_cpu_window.txt): confined to 24 CPUs the same run scanned 171-174 k
+// frames/s instead of 141-145 k; to 16 CPUs 120 k (too few to also run the runtime's own threads), to 32 CPUs 155-159 k.
 //
 // pick_cpu_window: pure arithmetic (tested on the CPU tier).  `local` = the CPUs next to the device in sysfs order
 // (e.g. "64-127,192-255": a socket's cores, then their SMT siblings), `gpu_index` of `gpus_on_node` GPUs share
-// them: the cores are cut into equal parts, part gpu_index is ours, and the window is its first `want` CPUs — cores
-// first, then the siblings of the same cores.  Every GPU of a node gets a disjoint window.
+// them: the cores are cut into equal parts, the window starts at part gpu_index and takes `want` physical cores from
+// there on (into the neighbours' parts when a part is smaller, wrapping inside the node); SMT siblings only when the
+// node has fewer cores than wanted.
 inline std::vector<int> pick_cpu_window(const std::vector<int> &local, int gpu_index, int gpus_on_node, int want) {
   std::vector<int> out;
   if (local.empty() || want <= 0) return out;
@@ -263,20 +264,26 @@ inline std::vector<int> pick_cpu_window(const std::vector<int> &local, int gpu_i
   const size_t first_len = ranges[0].second - ranges[0].first;
   // "cores, then their SMT siblings": exactly two equally long ranges (a node's sysfs local_cpulist, "64-127,192-255")
   const bool smt_layout = ranges.size() == 2 && first_len >= 2 && ranges[1].second - ranges[1].first == first_len;
-  const size_t pool_len = smt_layout ? first_len : local.size();          // the "cores" that get partitioned
+  const size_t pool_len = smt_layout ? first_len : local.size();          // the physical cores
   const size_t per = std::max<size_t>(1, pool_len / (size_t)gpus_on_node);
-  const size_t lo = std::min(pool_len, per * (size_t)gpu_index), hi = std::min(pool_len, lo + per);
-  for (size_t i = lo; i < hi && (int)out.size() < want; ++i) out.push_back(local[i]);
-  if (smt_layout)
-    for (size_t r = 1; r < ranges.size() && (int)out.size() < want; ++r)
-      if (ranges[r].second - ranges[r].first == first_len)
-        for (size_t i = lo; i < hi && (int)out.size() < want; ++i) out.push_back(local[ranges[r].first + i]);
+  const size_t lo = std::min(pool_len - 1, per * (size_t)gpu_index);
+  // `want` CORES starting at this GPU's part and running on into its neighbours' (wrapping inside the node): two
+  // hardware threads of one core are not two CPUs' worth of copy-out, and a window wider than a part only overlaps
+  // CPUs its neighbour cannot fill either under the same quota
+  const size_t n_cores = std::min<size_t>((size_t)want, pool_len);
+  for (size_t i = 0; i < n_cores; ++i) out.push_back(local[(lo + i) % pool_len]);
+  if (smt_layout)                                            // more wanted than the node has cores: their siblings
+    for (size_t i = 0; (int)out.size() < want && i < first_len; ++i) out.push_back(local[ranges[1].first + (lo + i) % pool_len]);
   return out;
 }
 
 // The window for the workers of `device`, or empty = do not pin.  MTGPU_CPU_WINDOW: "off" / "0" = never pin;
-// a number = that many CPUs; a cpulist ("64-87") = exactly those; unset = ceil(1.5 x cpu_budget()) CPUs, and only when
-// the budget is a real restriction (fewer CPUs' worth of time than CPUs the process may run on).
+// a number = that many CPUs; a cpulist ("64-87") = exactly those; unset = ceil(1.25 x cpu_budget()) cores, and only when
+// the budget is a real restriction (fewer CPUs' worth of time than CPUs the process may run on).  Measured on a 16-CPU
+// quota, three interleaved passes (profiles/r04_host_feed_ab_window.json): no window 147-157 k (64 x 1) / 139-145 k
+// (16 x 4) frames/s; 20 cores 163-166 k / 179-182 k every time; 24 cores 124-174 k / 142-183 k (two modes); 32 cores
+// 162-166 k / 165-166 k, throttled again; a window made of 16 cores + 8 of their own SMT siblings lost to no window at
+// 64 x 1 (r04_host_feed_ab_window_smt_siblings.json), hence physical cores only.
 inline std::vector<int> cpu_window_for_device(int device) {
   static std::mutex mu;
   static std::vector<std::pair<int, std::vector<int>>> cache;
@@ -300,7 +307,7 @@ inline std::vector<int> cpu_window_for_device(int device) {
     } else if (!env.empty()) want = std::max(0, std::atoi(env.c_str()));
     else {
       const int budget = cpu_budget();
-      want = budget < (int)allowed.size() ? (3 * budget + 1) / 2 : 0;
+      want = budget < (int)allowed.size() ? (5 * budget + 3) / 4 : 0;
     }
     if (want > 0 && want < (int)allowed.size()) {
       std::vector<int> local = allowed;

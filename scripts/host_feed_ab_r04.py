@@ -58,6 +58,13 @@ SETS = {
         "auto window, no gate": {"MTGPU_CPU_TOKENS": "0"},
         "window 32, 16 tokens": {"MTGPU_CPU_WINDOW": "32", "MTGPU_CPU_TOKENS": "16"},
     },
+    "window2": {
+        "no window (workers float over every CPU)": {"MTGPU_CPU_WINDOW": "off"},
+        "auto window (24 cores next to the device)": {},
+        "window 20 cores": {"MTGPU_CPU_WINDOW": "20"},
+        "window 32 cores": {"MTGPU_CPU_WINDOW": "32"},
+        "window = the far node's cores 0-23": {"MTGPU_CPU_WINDOW": "0-23"},
+    },
     "batch2": {
         "16 MiB batches": {"MTGPU_BATCH_MB": "16"},
         "8 MiB batches": {"MTGPU_BATCH_MB": "8"},
