@@ -65,6 +65,13 @@ SETS = {
         "window 32 cores": {"MTGPU_CPU_WINDOW": "32"},
         "window = the far node's cores 0-23": {"MTGPU_CPU_WINDOW": "0-23"},
     },
+    "tokens2": {      # CPU tokens once the workers are confined to 20 cores
+        "12 tokens (default)": {},
+        "10 tokens": {"MTGPU_CPU_TOKENS": "10"},
+        "14 tokens": {"MTGPU_CPU_TOKENS": "14"},
+        "16 tokens": {"MTGPU_CPU_TOKENS": "16"},
+        "no gate": {"MTGPU_CPU_TOKENS": "0"},
+    },
     "batch2": {
         "16 MiB batches": {"MTGPU_BATCH_MB": "16"},
         "8 MiB batches": {"MTGPU_BATCH_MB": "8"},
