@@ -72,6 +72,15 @@ SETS = {
         "16 tokens": {"MTGPU_CPU_TOKENS": "16"},
         "no gate": {"MTGPU_CPU_TOKENS": "0"},
     },
+    "pack2": {        # the copy-out loop once the feed is bound by the CPU budget (window + gate in force)
+        "default (AVX-512BW, NT stores, no software prefetch)": {},
+        "prefetch 1 KiB": {"MTGPU_PACK_PREFETCH": "1024"},
+        "prefetch 4 KiB": {"MTGPU_PACK_PREFETCH": "4096"},
+        "AVX2 loop": {"MTGPU_PACK": "avx2"},
+        "AVX2 loop, prefetch 1 KiB": {"MTGPU_PACK": "avx2", "MTGPU_PACK_PREFETCH": "1024"},
+        "ordinary stores": {"MTGPU_PACK_NT": "0"},
+        "scalar loop": {"MTGPU_PACK": "scalar"},
+    },
     "batch2": {
         "16 MiB batches": {"MTGPU_BATCH_MB": "16"},
         "8 MiB batches": {"MTGPU_BATCH_MB": "8"},
