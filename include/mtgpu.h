@@ -243,9 +243,7 @@ int mtgpu_merge_streams_device(mtgpu_ctx *ctx, const uint8_t *d_flags, const dou
  * One pipe per decoder thread — the reference's one-MotionScanner-per-worker model
  * (src/pipeline.cpp:186-197); pipes of one context may be used concurrently, so N worker threads need
  * N pipes but only ONE context per device.  Each batch's staging is one pinned block (plus a device mirror
- * without MT_LAYOUT_ZERO_COPY) — huge-page-advised memory first touched by the filling thread and page-locked
- * with hipHostRegister (MTGPU_PIN=malloc: hipHostMalloc, ~5 x slower to lock and unlock) — page-locked when the
- * batch is first used: creating a pipe pins one batch, the
+ * without MT_LAYOUT_ZERO_COPY), page-locked when the batch is first used: creating a pipe pins one batch, the
  * others follow on their first mtgpu_pipe_acquire (a few ms each), so S x T workers that start together are
  * not queued behind S x T x n_buffers page-locking calls, and a worker that never has more than one batch in
  * flight never pins the rest.

@@ -34,8 +34,6 @@
 #include <new>
 #include <vector>
 
-#include <sys/mman.h>
-
 #include "api_internal.h"
 #include "pack_simd.h"
 
@@ -64,7 +62,6 @@ struct mtgpu_batch {
   size_t hdr_bytes = 0;
   size_t stage_bytes = 0;             // [off | sd | records] part of the block
   size_t block_bytes = 0;             // the whole block: stage + pts / tag / flag arrays
-  bool registered = false;            // the block is ordinary memory registered with the runtime (MTGPU_PIN=register), not hipHostMalloc'ed
   uint64_t cap_records = 0, n_records = 0;
   uint64_t want_records = 0;          // capacity the block gets when it is pinned
   uint32_t cap_frames = 0, n_frames = 0;
@@ -83,13 +80,6 @@ struct mtgpu_pipe {
   bool zero_copy = false;
   bool blocking_events = false;  // MTGPU_EVENT_BLOCKING=1: collect sleeps on the batch's event instead of polling it
   bool eager_pin = false;        // MTGPU_PIPE_EAGER=1: pin every batch at creation (round 3 behaviour)
-  bool pin_by_register = true;   // staging = huge-page-advised malloc, first-touched by the filling thread, page-locked with
-                                 // hipHostRegister: 23-27 GB/s to lock and microseconds to unlock, where hipHostMalloc locks at
-                                 // ~5 GB/s and unlocks at ~7 (profiles/r04_pin_probe.json) — page-locking per worker 410-460 ms
-                                 // -> 14-47 ms, a 64-stream run 0.4 s shorter (profiles/r04_host_feed_ab_pin.json).  Such
-                                 // user-pointer mappings are re-validated by the driver if the kernel ever moves the pages (the
-                                 // workers and their first touch sit on the GPU's own NUMA node, so nothing asks it to).
-                                 // MTGPU_PIN=malloc: hipHostMalloc instead; also the automatic fallback if registering fails.
   long inject_submit_fail = 0;   // MTGPU_INJECT_SUBMIT_FAIL=k (tests): the k-th submit fails after its copies were queued
   long inject_collect_fail = 0;  // MTGPU_INJECT_COLLECT_FAIL=k (tests): the k-th collect's event wait "fails";
                                  // negative: its stream drain "fails" as well (the batch is poisoned)
@@ -108,16 +98,10 @@ namespace {
 using mtgpu::fail;
 using mtgpu::hip_fail;
 
-void free_host_block(unsigned char *p, bool registered) {
-  if (!p) return;
-  if (registered) { (void)hipHostUnregister(p); std::free(p); }
-  else (void)hipHostFree(p);
-}
-
 void free_batch(mtgpu_batch *b) {
   if (!b) return;
   if (b->stream) (void)hipStreamSynchronize(b->stream);
-  free_host_block(b->h_stage, b->registered);
+  if (b->h_stage) (void)hipHostFree(b->h_stage);
   if (b->d_stage) (void)hipFree(b->d_stage);
   if (b->done) (void)hipEventDestroy(b->done);
   if (b->stream && b->own_stream) (void)hipStreamDestroy(b->stream);
@@ -152,23 +136,7 @@ int pin_block(mtgpu_batch *b, uint64_t records, bool inject_failure = false) {
   const size_t sbytes = stage_bytes_for(b->cap_frames, records, b->rec_bytes, &hdr);
   const size_t bytes = sbytes + aux_bytes_for(b->cap_frames);
   const size_t nf = (size_t)b->cap_frames + 1;
-  const bool by_register = b->owner && b->owner->pin_by_register;
-  if (by_register) {
-    const size_t huge = (size_t)2 << 20, rounded = (bytes + huge - 1) & ~(huge - 1);
-    h_new = static_cast<unsigned char *>(std::aligned_alloc(huge, rounded));
-    if (!h_new) return fail(MT_ERR_NOMEM, "out of host memory");
-    (void)madvise(h_new, rounded, MADV_HUGEPAGE);
-    std::memset(h_new, 0, rounded);                     // first touch by the filling thread: the pages land next to it
-    hipError_t e = hipHostRegister(h_new, rounded, hipHostRegisterDefault);
-    if (e != hipSuccess) {                              // e.g. a locked-memory limit: driver-allocated pinned memory from now on
-      (void)hipGetLastError();
-      std::free(h_new);
-      h_new = nullptr;
-      b->owner->pin_by_register = false;
-    }
-  }
-  const bool registered_now = h_new != nullptr;
-  if (!registered_now) PIPE_TRY(hipHostMalloc(reinterpret_cast<void **>(&h_new), bytes, hipHostMallocDefault));
+  PIPE_TRY(hipHostMalloc(reinterpret_cast<void **>(&h_new), bytes, hipHostMallocDefault));
   if (inject_failure) { rc = fail(MT_ERR_NOMEM, "injected allocation failure (MTGPU_INJECT_GROW_FAIL)"); goto bad; }
   if (b->zero_copy) {
     // no device mirror: the kernel reads the pinned block through its device-visible address and writes the
@@ -178,10 +146,9 @@ int pin_block(mtgpu_batch *b, uint64_t records, bool inject_failure = false) {
     PIPE_TRY(hipMalloc(reinterpret_cast<void **>(&d_new), bytes));
     dev_view = d_new;
   }
-  free_host_block(b->h_stage, b->registered);
+  if (b->h_stage) (void)hipHostFree(b->h_stage);
   if (b->d_stage) (void)hipFree(b->d_stage);
   b->h_stage = h_new;
-  b->registered = registered_now;
   b->d_stage = d_new;
   b->hdr_bytes = hdr;
   b->stage_bytes = sbytes;
@@ -200,7 +167,7 @@ int pin_block(mtgpu_batch *b, uint64_t records, bool inject_failure = false) {
   b->cap_records = records;
   return MT_OK;
 bad:
-  free_host_block(h_new, registered_now);
+  if (h_new) (void)hipHostFree(h_new);
   if (d_new) (void)hipFree(d_new);
   return rc;
 }
@@ -277,7 +244,6 @@ int mtgpu_pipe_create_layout(mtgpu_ctx *ctx, uint64_t max_records_per_batch, uin
   p->zero_copy = (layout & MT_LAYOUT_ZERO_COPY) != 0;
   if (const char *v = std::getenv("MTGPU_EVENT_BLOCKING")) p->blocking_events = std::atol(v) != 0;
   if (const char *v = std::getenv("MTGPU_PIPE_EAGER")) p->eager_pin = std::atol(v) != 0;
-  if (const char *v = std::getenv("MTGPU_PIN")) p->pin_by_register = std::strcmp(v, "malloc") != 0;
   if (const char *v = std::getenv("MTGPU_INJECT_SUBMIT_FAIL")) p->inject_submit_fail = std::atol(v);
   if (const char *v = std::getenv("MTGPU_INJECT_GROW_FAIL")) p->inject_grow_fail = std::atol(v) != 0;
   if (const char *v = std::getenv("MTGPU_INJECT_COLLECT_FAIL")) p->inject_collect_fail = std::atol(v);

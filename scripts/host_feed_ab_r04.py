@@ -81,12 +81,6 @@ SETS = {
         "ordinary stores": {"MTGPU_PACK_NT": "0"},
         "scalar loop": {"MTGPU_PACK": "scalar"},
     },
-    "pin": {          # how the staging is page-locked
-        "hipHostMalloc, on first use (default)": {},
-        "hipHostMalloc, all at creation": {"MTGPU_PIPE_EAGER": "1"},
-        "malloc + hipHostRegister, on first use": {"MTGPU_PIN": "register"},
-        "malloc + hipHostRegister, all at creation": {"MTGPU_PIN": "register", "MTGPU_PIPE_EAGER": "1"},
-    },
     "batch2": {
         "16 MiB batches": {"MTGPU_BATCH_MB": "16"},
         "8 MiB batches": {"MTGPU_BATCH_MB": "8"},
