@@ -915,3 +915,42 @@ def test_pipe_batches_run_on_the_contexts_stream_pool(gpu_scanner_factory, monke
         assert s.stats()["hip_streams"] == (9 if pooled else 1)
         for pp in pipes:
             pp.close()
+
+
+@pytest.mark.parametrize("layout", [m._abi.LAYOUT_COMPACT8 | m._abi.LAYOUT_ZERO_COPY, m._abi.LAYOUT_AOS40 | m._abi.LAYOUT_ZERO_COPY,
+                                    m._abi.LAYOUT_COMPACT8])
+def test_pipe_staging_reuse_stress(gpu_scanner_factory, layout):
+    """The same three staging blocks refilled ~1500 times with different frames, every flag checked: what the host
+    writes into a block (non-temporal stores for compact staging) must be what the NEXT kernel on that block reads,
+    and what that kernel writes (flag bytes, straight into pinned memory with zero-copy) what the host reads after
+    the batch's event — no stale line from the block's previous use on either side.  (Round 4: registered
+    user-pointer staging failed exactly this, once, in the soak; driver-allocated pinned staging must never.)"""
+    p = ob.params_from_config(640, 480, vectors_needed=1, clusters_needed=1, mv_threshold_sq=4.0)
+    s = gpu_scanner_factory(p)
+    rng = np.random.RandomState(layout + 5)
+    # a pool of small frames with known answers, half of them "motion"
+    pool = []
+    for k in range(64):
+        n = int(rng.randint(1, 400))
+        mv = np.zeros(n, dtype=m.MV_DTYPE)
+        mv["dst_x"], mv["dst_y"] = rng.randint(0, 640, size=n), rng.randint(32, 448, size=n)
+        mv["src_x"], mv["src_y"] = mv["dst_x"] - 1, mv["dst_y"]                       # below the threshold
+        if k & 1:                                                                     # two neighbouring cells with a real vector
+            gx, gy = int(rng.randint(2, 36)), int(rng.randint(3, 26))
+            for j, (cx, cy) in enumerate(((gx, gy), (gx + 1, gy))):
+                i = int(rng.randint(0, n)) if n > 2 else j % n
+                mv["dst_x"][i], mv["dst_y"][i] = cx * 16 + 5, cy * 16 + 5
+                mv["src_x"][i], mv["src_y"][i] = cx * 16 + 5 - 9, cy * 16 + 5
+        pool.append(mv)
+    b = m.FrameBatch.from_frames(pool)
+    want_pool = ob.scan_frames(p, b.mv, b.frame_off, b.has_sd)
+    assert 10 < want_pool.sum() < 54
+    pipe = m.ScanPipe(s, 4 * 400, 4, 3, layout=layout)
+    order = rng.randint(0, 64, size=6000)
+    for t, k in enumerate(order):
+        pipe.feed(pool[k], float(t), tag=int(k))
+    got = pipe.drain()
+    pipe.close()
+    assert len(got) == 6000
+    bad = [(i, tag) for i, (_, fl, tag) in enumerate(got) if fl != want_pool[tag]]
+    assert not bad, bad[:10]

@@ -73,7 +73,8 @@ def test_soak_random_parity(gpu_scanner_factory):
             got = s.check_frames_device_compact(d_rec[: len(rec) * 8], torch.from_numpy(off.astype(np.int64)).cuda(),
                                                 torch.from_numpy(sd).cuda()).cpu().numpy()
             assert np.array_equal(got, want), ("compact", seed, it, w, h, kw, s.plan, knobs)
-        if it % 5 == 0:                                 # the pinned pipe (zero-copy compact staging)
+        if it % 2 == 0:                                 # the pinned pipe (zero-copy compact staging): every other configuration
+                                                        # since round 4 — staging reuse is where a visibility fault would show
             pipe = m.ScanPipe(s, int(rng.choice([500, 5000, 50000])), int(rng.choice([1, 4, 32])), int(rng.choice([1, 2, 3])))
             for f in range(n_frames):
                 fr = mv[int(off[f]):int(off[f + 1])]
