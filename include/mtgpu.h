@@ -219,10 +219,14 @@ int mtgpu_merge_timestamps_device(mtgpu_ctx *ctx, const double *d_ts, uint64_t n
  *   d_pts         n_frames doubles: pts of each frame in seconds (:361)
  *   d_stream_off  S+1 frame offsets (device)
  *   d_mp          S merge-parameter blocks (device)
- *   d_ts          workspace, n_frames doubles (device): compacted timestamps, stream-major
- *   d_seg         S * seg_cap segments (device): stream s writes at d_seg[s*seg_cap]
+ *   d_ts          workspace, 2 * n_frames doubles (device), n_frames = d_stream_off[S]: stream s keeps its
+ *                 compacted timestamps in [2a, 2a + (b-a)) and its per-segment durations in [2a + (b-a), 2b),
+ *                 a = d_stream_off[s], b = d_stream_off[s+1] (every flagged frame may be a segment of its own);
+ *                 contents unspecified afterwards; must stay allocated until the call has finished on `stream`
+ *   d_seg         S * seg_cap segments (device): stream s writes at d_seg[s*seg_cap], never beyond seg_cap
  *   d_res         S results (device); n_segments > seg_cap signals truncation
- * Asynchronous on `stream`.
+ * Asynchronous on `stream`.  (tests/c/abi_buffer_canaries.c allocates every buffer of this header at exactly
+ * its stated size with a canary behind it.)
  */
 int mtgpu_merge_streams_device(mtgpu_ctx *ctx, const uint8_t *d_flags, const double *d_pts,
                                const uint64_t *d_stream_off, uint32_t n_streams,

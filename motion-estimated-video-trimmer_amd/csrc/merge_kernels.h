@@ -15,7 +15,7 @@ struct MergeLaunch {
   unsigned long long n_frames_total;
   const mt_merge_params *mp;              // n_streams
   int job_semantics;
-  double *ts_ws;                          // 2 * n_frames_total doubles
+  double *ts_ws;                          // 2 * n_frames_total doubles (include/mtgpu.h: d_ts)
   mt_segment *seg;                        // n_streams * seg_cap
   unsigned long long seg_cap;
   mt_merge_result *res;                   // n_streams

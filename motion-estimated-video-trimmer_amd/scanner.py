@@ -375,7 +375,14 @@ class MotionScanner:
             self._ctx, None if flags is None else flags.data_ptr(), pts.data_ptr(),
             stream_off.data_ptr(), n_streams, merge_params.data_ptr(), 1 if job_semantics else 0,
             ws.data_ptr(), seg.data_ptr(), seg_cap, res.data_ptr(), st))
-        self._keep = ws  # keep the workspace alive until the stream has consumed it
+        if out is None:
+            # the workspace must outlive the kernel that was just queued: it is held until an event recorded
+            # behind the launch on ITS stream has passed (torch's caching allocator knows nothing of a raw
+            # hipStream_t handed in by the caller, and several merges may be queued back to back)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev) if stream is None else torch.cuda.ExternalStream(stream, device=dev))
+            self._held = [(e, w) for e, w in getattr(self, "_held", []) if not e.query()]
+            self._held.append((ev, ws))
         return seg, res
 
 
