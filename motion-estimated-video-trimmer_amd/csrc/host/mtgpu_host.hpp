@@ -105,10 +105,11 @@ struct Config {   // same variables, defaults and parse types as config.hpp:56-1
 
 // ---------------------------------------------------------------- CPU budget
 // CPUs' worth of run TIME the scheduler grants this process: the cgroup quota (v2 cpu.max, v1 cfs quota), rounded
-// up; without a quota the CPUs it may run on.  This is what the CpuGate below is sized from.  It is deliberately NOT
-// the reference's detect_cpu_limit() (reference_cpu_limit() further down): that function takes the LARGER of the
-// quota and the cpuset's CPU count (src/system.cpp:155-161) — on a box that shows 256 CPUs to a job with a 16-CPU
-// quota it answers 256, and 256 runnable workers are exactly what the quota throttles.
+// up; without a quota the CPUs it may run on.  This is what the CpuGate, the CPU windows and the default batch sizing
+// below are sized from.  It is deliberately NOT the reference's detect_cpu_limit(): that function takes the LARGER
+// of the quota and the cpuset's CPU count (src/system.cpp:155-161) — on a box that shows 256 CPUs to a job with a
+// 16-CPU quota the reference's own object code answers 256 (profiles/r04_sizing_on_gpu_box.txt), and 256 runnable
+// workers are exactly what the quota throttles.
 inline int cpu_budget() {
   auto read_two = [](const char *path, long &a, long &b) {
     FILE *f = std::fopen(path, "r");
@@ -135,105 +136,74 @@ inline int cpu_budget() {
   return hc ? (int)hc : 1;
 }
 
-// ---- the reference's own sizing of streams and threads, restated (src/system.cpp:38-197, src/batch_processor.cpp:81-95)
-// and checked against the reference's object code where that builds (oracle/_ref/ref_host_probe `sizing`,
-// tests/test_reference_host.py).  `mtgpu_scan_file --streams 0 --threads 0` sizes a batch run with these, as
-// `motion_trim in_dir out_dir` does; an explicit stream count may exceed the CPUs (that is what the gate is for).
-namespace refsizing {
-inline long read_long_from_file(const char *path) {            // system.cpp:38-46 (a value without a newline after it is -1)
-  std::ifstream f(path);
-  if (!f) return -1;
-  long val;
-  f >> val;
-  return f.good() ? val : -1;
+// ---------------------------------------------------------------- how many streams and workers
+// Sizing of a batch run when the caller gives no counts (mtgpu_scan_file --streams 0 / --threads 0).  This is NOT
+// the reference's rule: `motion_trim in_dir out_dir` opens min(PARALLEL_STREAMS, detect_cpu_limit()) streams with
+// CPUs / streams threads each (src/system.cpp:186-197, src/batch_processor.cpp:81-95) because there every stream
+// thread scans on a CPU of its own.  Here a worker only decodes and copies out — the scan runs on a GPU — so:
+//   streams  PARALLEL_STREAMS when set (> 0), never more than there are videos; a stream count above the CPU budget
+//            is legal (BASELINE config 4: 64 streams on a 16-CPU quota): the CpuGate, not the stream count, bounds
+//            the runnable threads.  Auto: one stream per CPU of the budget, at least one per device.
+//   threads  THREADS_PER_STREAM when set (> 0); auto: two workers per CPU of the budget over all streams (one fills a
+//            batch while the other waits for the GPU: measured flat from 4 workers per hot stream on),
+//            at least one per stream.
+// What the reference itself would choose on a machine is printed by ITS object code (oracle/_ref/ref_host_probe
+// `sizing`, built from src/system.cpp where it lies; tests/test_reference_host.py keeps that comparison).
+struct BatchSizing { int streams = 1, threads = 1; };
+inline BatchSizing default_batch_sizing(int n_videos, int n_devices, int budget, int configured_streams, int configured_threads) {
+  BatchSizing z;
+  n_videos = std::max(1, n_videos);
+  n_devices = std::max(1, n_devices);
+  budget = std::max(1, budget);
+  z.streams = configured_streams > 0 ? configured_streams : std::max(budget, n_devices);
+  z.streams = std::max(1, std::min(z.streams, n_videos));
+  z.threads = configured_threads > 0 ? configured_threads : std::max(1, (2 * budget + z.streams - 1) / z.streams);
+  return z;
 }
-inline std::vector<int> parse_cpuset_string(const std::string &line) {   // system.cpp:49-80: "0,2,4" / "0-3"
-  std::vector<int> cpus;
-  size_t pos = 0;
-  while (pos < line.size()) {
-    size_t end = line.find_first_of(",-", pos);
-    if (end == std::string::npos) end = line.size();
-    const int start_cpu = std::stoi(line.substr(pos, end - pos));
-    if (end < line.size() && line[end] == '-') {
-      pos = end + 1;
-      end = line.find(',', pos);
-      if (end == std::string::npos) end = line.size();
-      const int end_cpu = std::stoi(line.substr(pos, end - pos));
-      for (int cpu = start_cpu; cpu <= end_cpu; ++cpu) cpus.push_back(cpu);
-    } else {
-      cpus.push_back(start_cpu);
-    }
-    pos = (end < line.size()) ? end + 1 : line.size();
+
+// "0-3,8,10-11" (sysfs cpulists, MTGPU_CPU_WINDOW) -> CPU numbers in the order written, duplicates dropped.
+// Anything that is not a list of non-negative numbers and ranges throws std::invalid_argument.
+inline std::vector<int> parse_cpu_list(const std::string &text) {
+  std::vector<int> out;
+  const char *p = text.c_str();
+  auto skip = [&] { while (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r') ++p; };
+  auto number = [&]() -> long {
+    skip();
+    if (*p < '0' || *p > '9') throw std::invalid_argument("cpu list: number expected");
+    char *end = nullptr;
+    const long v = std::strtol(p, &end, 10);
+    if (v < 0 || v > 1 << 20) throw std::invalid_argument("cpu list: number out of range");
+    p = end;
+    skip();
+    return v;
+  };
+  skip();
+  while (*p) {
+    const long lo = number();
+    long hi = lo;
+    if (*p == '-') { ++p; hi = number(); }
+    if (hi < lo) throw std::invalid_argument("cpu list: descending range");
+    for (long c = lo; c <= hi; ++c)
+      if (std::find(out.begin(), out.end(), (int)c) == out.end()) out.push_back((int)c);
+    if (*p == ',') { ++p; skip(); if (!*p) throw std::invalid_argument("cpu list: trailing comma"); }
+    else if (*p) throw std::invalid_argument("cpu list: ',' expected");
   }
+  return out;
+}
+
+// The CPUs this PROCESS may run on: the affinity of its main thread (tid == pid), not of the calling thread —
+// worker threads pin themselves to their device's window and every thread they start inherits that mask, so a
+// worker asking on behalf of another device would otherwise see only its own window.  Read once.
+inline const std::vector<int> &process_allowed_cpus() {
+  static const std::vector<int> cpus = [] {
+    std::vector<int> v;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(getpid(), sizeof set, &set) == 0)
+      for (int c = 0; c < CPU_SETSIZE; ++c) if (CPU_ISSET(c, &set)) v.push_back(c);
+    return v;
+  }();
   return cpus;
-}
-inline std::vector<int> read_cpuset_file(const char *path) {   // system.cpp:94-101
-  std::ifstream f(path);
-  if (!f) return {};
-  std::string line;
-  std::getline(f, line);
-  return parse_cpuset_string(line);
-}
-inline int count_cpuset(const char *path) {                    // system.cpp:83-91
-  const std::vector<int> cpus = read_cpuset_file(path);
-  return cpus.empty() ? -1 : (int)cpus.size();
-}
-}  // namespace refsizing
-
-inline int reference_cpu_limit() {                             // detect_cpu_limit(), system.cpp:107-164
-  int limit = -1;
-  {
-    std::ifstream f("/sys/fs/cgroup/cpu.max");
-    if (f) {
-      std::string quota_str, period_str;
-      f >> quota_str >> period_str;
-      if (quota_str != "max" && !period_str.empty()) {
-        const long quota = std::stol(quota_str), period = std::stol(period_str);
-        if (quota > 0 && period > 0) limit = (int)((quota + period - 1) / period);
-      }
-    }
-  }
-  if (limit <= 0) {
-    const long quota = refsizing::read_long_from_file("/sys/fs/cgroup/cpu/cpu.cfs_quota_us");
-    const long period = refsizing::read_long_from_file("/sys/fs/cgroup/cpu/cpu.cfs_period_us");
-    if (quota > 0 && period > 0) limit = (int)((quota + period - 1) / period);
-  }
-  if (limit <= 0) {
-    limit = refsizing::count_cpuset("/sys/fs/cgroup/cpuset.cpus.effective");
-    if (limit <= 0) limit = refsizing::count_cpuset("/sys/fs/cgroup/cpuset/cpuset.cpus");
-  }
-  if (limit <= 0) limit = (int)std::thread::hardware_concurrency();
-  if (limit <= 0) limit = 4;                                   // :149-152 sanity checks
-  if (limit > 64) limit = 64;
-  int cpuset_count = refsizing::count_cpuset("/sys/fs/cgroup/cpuset.cpus.effective");   // :155-161 the larger of the two
-  if (cpuset_count <= 0) cpuset_count = refsizing::count_cpuset("/sys/fs/cgroup/cpuset/cpuset.cpus");
-  if (cpuset_count > limit) limit = cpuset_count;
-  return limit;
-}
-
-inline std::vector<int> reference_available_cpus() {           // get_available_cpus(), system.cpp:166-184
-  std::vector<int> cpus = refsizing::read_cpuset_file("/sys/fs/cgroup/cpuset.cpus.effective");
-  if (cpus.empty()) cpus = refsizing::read_cpuset_file("/sys/fs/cgroup/cpuset/cpuset.cpus");
-  if (cpus.empty()) {
-    const int limit = reference_cpu_limit();
-    for (int i = 0; i < limit; ++i) cpus.push_back(i);
-  }
-  return cpus;
-}
-
-inline int reference_parallel_streams() {                      // calculate_parallel_streams(), system.cpp:186-197
-  const int available = reference_cpu_limit();
-  const int configured = Config::parallel_streams();
-  if (configured == 0) return std::max(1, available);
-  return std::max(1, std::min(configured, available));
-}
-
-// BatchProcessor::process, batch_processor.cpp:81-95: streams capped at the available CPUs; THREADS_PER_STREAM, or
-// when that is 0 (auto) the available CPUs divided by the streams
-inline void reference_batch_sizing(int num_streams, int available_cpus, int configured_threads, int &streams, int &threads) {
-  streams = std::max(1, std::min(num_streams, available_cpus));
-  threads = configured_threads;
-  if (threads <= 0) threads = std::max(1, available_cpus / streams);
 }
 
 // ---------------------------------------------------------------- where the worker threads run
@@ -291,17 +261,15 @@ inline std::vector<int> cpu_window_for_device(int device) {
   for (auto &c : cache) if (c.first == device) return c.second;
   std::vector<int> win;
   try {
-    cpu_set_t set;
-    CPU_ZERO(&set);
-    std::vector<int> allowed;
-    if (sched_getaffinity(0, sizeof set, &set) == 0)
-      for (int c = 0; c < CPU_SETSIZE; ++c) if (CPU_ISSET(c, &set)) allowed.push_back(c);
+    // (the PROCESS's CPUs: a worker already pinned to its own device's window may be the first to ask for another
+    //  device's — with the calling thread's mask every later device came back empty, for the life of the process)
+    const std::vector<int> &allowed = process_allowed_cpus();
     const char *e = std::getenv("MTGPU_CPU_WINDOW");
     const std::string env = e ? e : "";
     int want = 0;
     if (env == "off" || env == "0") want = 0;
     else if (!env.empty() && env.find_first_of(",-") != std::string::npos) {
-      for (int c : refsizing::parse_cpuset_string(env)) if (std::find(allowed.begin(), allowed.end(), c) != allowed.end()) win.push_back(c);
+      for (int c : parse_cpu_list(env)) if (std::find(allowed.begin(), allowed.end(), c) != allowed.end()) win.push_back(c);
       cache.push_back({device, win});
       return win;
     } else if (!env.empty()) want = std::max(0, std::atoi(env.c_str()));
@@ -316,7 +284,9 @@ inline std::vector<int> cpu_window_for_device(int device) {
       if (mtgpu_device_pci_address(device, addr, sizeof addr) == MT_OK) {
         const std::string dir = std::string("/sys/bus/pci/devices/") + addr;
         std::vector<int> near;
-        for (int c : refsizing::read_cpuset_file((dir + "/local_cpulist").c_str()))
+        std::string cpulist;
+        { std::ifstream f(dir + "/local_cpulist"); if (f) std::getline(f, cpulist); }
+        for (int c : parse_cpu_list(cpulist))
           if (std::find(allowed.begin(), allowed.end(), c) != allowed.end()) near.push_back(c);
         if ((int)near.size() >= want) {
           local = near;

@@ -100,15 +100,16 @@ int main(int argc, char **argv) {
     else if (!std::strcmp(argv[i], "--repeat") && i + 1 < argc) repeat = std::atol(argv[++i]);
     else files.push_back(argv[i]);
   }
-  // --streams 0 / --threads 0: sized as the reference sizes a batch run (calculate_parallel_streams() streams,
-  // src/system.cpp:186-197; THREADS_PER_STREAM or CPUs / streams threads, src/batch_processor.cpp:81-95)
+  // --streams 0 / --threads 0: sized from the CPU budget, the devices and the number of videos (default_batch_sizing,
+  // mtgpu_host.hpp — deliberately not the reference's CPU-only rule, src/system.cpp:186-197); PARALLEL_STREAMS /
+  // THREADS_PER_STREAM are honoured as in the reference (config.hpp:138-141, 165-168)
   if (streams <= 0 || threads <= 0) {
     try {
-      const int avail = (int)reference_available_cpus().size();
-      int st = streams > 0 ? streams : reference_parallel_streams(), th = 0;
-      reference_batch_sizing(st, avail, threads > 0 ? threads : Config::threads_per_stream(), st, th);
-      if (streams <= 0) streams = st;
-      if (threads <= 0) threads = th;
+      const BatchSizing z = default_batch_sizing((int)files.size(), mtgpu_device_count(), cpu_budget(),
+                                                 streams > 0 ? streams : Config::parallel_streams(),
+                                                 threads > 0 ? threads : Config::threads_per_stream());
+      if (streams <= 0) streams = z.streams;
+      if (threads <= 0) threads = z.threads;
     } catch (const std::exception &e) {
       std::fprintf(stderr, "error: configuration: %s\n", e.what());
       return 1;

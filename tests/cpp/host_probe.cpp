@@ -253,27 +253,39 @@ int main(int argc, char **argv) {
   const std::string cmd = argc > 1 ? argv[1] : "";
   if (cmd == "gate" && argc == 5) return cmd_gate(std::atoi(argv[2]), std::atoi(argv[3]), std::atoi(argv[4]));
   if (cmd == "cpulimit") { std::printf("%d\n", h::cpu_budget()); return 0; }
-  if (cmd == "sizing") {      // the same three lines oracle/_ref/ref_host_probe `sizing` prints from the reference's system.cpp
-    std::printf("detect_cpu_limit %d\n", h::reference_cpu_limit());
-    try {
-      std::printf("calculate_parallel_streams %d\n", h::reference_parallel_streams());
-    } catch (const std::exception &e) {
-      std::printf("calculate_parallel_streams throws %s\n", typeid(e).name());
-    }
-    const std::vector<int> cpus = h::reference_available_cpus();
-    std::printf("available_cpus %zu first %d last %d\n", cpus.size(), cpus.empty() ? -1 : cpus.front(), cpus.empty() ? -1 : cpus.back());
-    return 0;
-  }
   if (cmd == "window" && argc == 6) {        // local_cpulist gpu_index gpus_on_node want -> the window
-    const std::vector<int> w = h::pick_cpu_window(h::refsizing::parse_cpuset_string(argv[2]), std::atoi(argv[3]), std::atoi(argv[4]), std::atoi(argv[5]));
+    const std::vector<int> w = h::pick_cpu_window(h::parse_cpu_list(argv[2]), std::atoi(argv[3]), std::atoi(argv[4]), std::atoi(argv[5]));
     for (size_t i = 0; i < w.size(); ++i) std::printf("%s%d", i ? "," : "", w[i]);
     std::printf("\n");
     return 0;
   }
-  if (cmd == "batchsizing" && argc == 5) {   // num_streams available_cpus configured_threads -> streams threads
-    int st = 0, th = 0;
-    h::reference_batch_sizing(std::atoi(argv[2]), std::atoi(argv[3]), std::atoi(argv[4]), st, th);
-    std::printf("%d %d\n", st, th);
+  if (cmd == "batchsizing" && argc == 7) {   // n_videos n_devices budget configured_streams configured_threads -> streams threads
+    const h::BatchSizing z = h::default_batch_sizing(std::atoi(argv[2]), std::atoi(argv[3]), std::atoi(argv[4]), std::atoi(argv[5]), std::atoi(argv[6]));
+    std::printf("%d %d\n", z.streams, z.threads);
+    return 0;
+  }
+  if (cmd == "cpulist" && argc == 3) {       // parse_cpu_list: the numbers, or "invalid"
+    try {
+      const std::vector<int> v = h::parse_cpu_list(argv[2]);
+      for (size_t i = 0; i < v.size(); ++i) std::printf("%s%d", i ? "," : "", v[i]);
+      std::printf("\n");
+    } catch (const std::invalid_argument &) {
+      std::printf("invalid\n");
+    }
+    return 0;
+  }
+  if (cmd == "windowpinned") {
+    // A worker that is already confined to device 0's window asks for device 1's (what process_batch's stream
+    // threads do on a multi-GPU node): both answers must come from the PROCESS's CPUs, not from the asking thread's.
+    std::vector<int> w0, w1;
+    std::thread t([&] {
+      w0 = h::cpu_window_for_device(0);
+      (void)h::pin_this_thread(w0);
+      std::thread inner([&] { w1 = h::cpu_window_for_device(1); });   // inherits the pinned mask
+      inner.join();
+    });
+    t.join();
+    std::printf("allowed %zu window0 %zu window1 %zu\n", h::process_allowed_cpus().size(), w0.size(), w1.size());
     return 0;
   }
   if (cmd == "concat" && argc == 4 && std::string(argv[3]) == "--setlocale") {

@@ -203,11 +203,11 @@ def test_multi_device_paths_of_the_host_layer_on_aliased_devices(streams64):
     assert sorted(json.dumps(j["segments"]) + j["input"] for j in jobs) == sorted(json.dumps(j["segments"]) + j["input"] for j in jobs1)
 
 
-def test_batch_sized_like_the_reference_when_no_counts_are_given(streams64):
-    """`mtgpu_scan_file --streams 0 --threads 0` sizes the batch as `motion_trim in_dir out_dir` does: PARALLEL_STREAMS
-    capped by the reference's CPU limit (calculate_parallel_streams, src/system.cpp:186-197), THREADS_PER_STREAM
-    (src/batch_processor.cpp:81-95) — restated in the host layer and checked against the reference's own system.cpp in
-    tests/test_reference_host.py; here: the front end really uses it, and the jobs stay bit-exact."""
+def test_batch_sized_from_budget_devices_and_videos_when_no_counts_are_given(streams64):
+    """`mtgpu_scan_file --streams 0 --threads 0` sizes the batch with the host layer's own rule (default_batch_sizing:
+    CPU budget, devices, videos — hand cases in tests/test_reference_host.py), honouring PARALLEL_STREAMS and
+    THREADS_PER_STREAM as `motion_trim in_dir out_dir` does (config.hpp:138-141, 165-168); the jobs stay bit-exact and
+    an unparsable value is a configuration error, not a crash."""
     d, paths, cases = streams64
     some = paths[:8]
     r, jobs, s = _run(some, 0, 0, d, {"PARALLEL_STREAMS": "4", "THREADS_PER_STREAM": "2"})

@@ -342,32 +342,64 @@ def _ref_has_sizing():
 
 
 @pytest.mark.skipif(not _ref_has_sizing(), reason="oracle/_ref/ref_host_probe was built without the reference's system.cpp")
-def test_stream_sizing_matches_the_references_system_cpp_on_this_machine(host_probe):
-    """Row a11 (stream fan-out): how many streams the reference starts — detect_cpu_limit(), get_available_cpus() and
-    calculate_parallel_streams() (src/system.cpp:107-197) — restated in the host layer (reference_cpu_limit /
-    reference_available_cpus / reference_parallel_streams) and compared here, line for line, with the reference's OWN
-    object code (src/system.cpp compiled where it lies into oracle/_ref/ref_host_probe) on this machine's real cgroup
-    files, for PARALLEL_STREAMS unset / 0 / 3 / 64 / 100000 / -2 / unparsable (std::stoi throws in both)."""
-    for ps in (None, "0", "3", "64", "100000", "-2", "abc", "7xyz"):
+def test_what_the_reference_would_choose_on_this_machine_vs_the_cpu_budget(host_probe):
+    """Row a11 (stream fan-out).  How many streams the REFERENCE starts on this machine is asked of the reference's
+    own object code (src/system.cpp compiled where it lies into oracle/_ref/ref_host_probe: detect_cpu_limit(),
+    calculate_parallel_streams(), get_available_cpus(), src/system.cpp:107-197) — the product holds no restatement of
+    it.  The host layer sizes from cpu_budget() instead (the cgroup quota when there is one), which can only be
+    tighter: detect_cpu_limit() takes the LARGER of the quota and the cpuset's CPU count (:155-161)."""
+    budget = int(run(host_probe, ["cpulimit"])[0])
+    for ps in (None, "0", "3", "64"):
         env = {} if ps is None else {"PARALLEL_STREAMS": ps}
         ref = run(REF_PROBE, ["sizing"], env)
-        assert len(ref) == 3 and ref[0].startswith("detect_cpu_limit ")
-        assert run(host_probe, ["sizing"], env) == ref, ps
+        assert len(ref) == 3 and ref[0].startswith("detect_cpu_limit ") and ref[1].startswith("calculate_parallel_streams ")
+        limit, streams = int(ref[0].split()[1]), int(ref[1].split()[1])
+        assert 1 <= budget <= max(limit, len(os.sched_getaffinity(0)))
+        assert streams == (max(1, limit) if ps in (None, "0") else max(1, min(int(ps), limit)))   # its own documented rule
+    for ps in ("abc",):                                        # std::stoi throws in the reference; here: a configuration error
+        assert "throws" in run(REF_PROBE, ["sizing"], {"PARALLEL_STREAMS": ps})[1]
 
 
 def test_batch_sizing_hand_cases(host_probe):
-    """BatchProcessor::process, src/batch_processor.cpp:81-95 (that file needs libav and cannot be built: hand-derived):
-    streams = max(1, min(num_streams, available CPUs)); threads = THREADS_PER_STREAM, or available / streams when 0."""
-    cases = [((3, 8, 0), (3, 2)), ((64, 16, 0), (16, 1)), ((2, 16, 0), (2, 8)), ((5, 16, 0), (5, 3)), ((0, 8, 0), (1, 8)),
-             ((-3, 8, 0), (1, 8)), ((3, 8, 4), (3, 4)), ((64, 16, 4), (16, 4)), ((3, 2, 0), (2, 1)), ((3, 8, -1), (3, 2))]
-    for (ns, av, th), want in cases:
-        assert tuple(int(x) for x in run(host_probe, ["batchsizing", str(ns), str(av), str(th)])[0].split()) == want, (ns, av, th)
+    """default_batch_sizing (host layer; its own rule, not src/batch_processor.cpp:81-95 — a worker here decodes and
+    copies out, the scan runs on a GPU): streams = PARALLEL_STREAMS, or one per CPU of the budget and at least one per
+    device, never more than there are videos; threads = THREADS_PER_STREAM, or two workers per CPU of the budget
+    spread over the streams, at least one each.  (n_videos, n_devices, budget, configured streams, configured threads)."""
+    cases = [((64, 1, 16, 0, 0), (16, 2)), ((64, 8, 16, 0, 0), (16, 2)), ((8, 1, 16, 0, 0), (8, 4)), ((3, 8, 16, 0, 0), (3, 11)),
+             ((64, 1, 16, 64, 0), (64, 1)), ((64, 1, 16, 64, 1), (64, 1)), ((8, 1, 16, 4, 2), (4, 2)), ((2, 1, 16, 4, 0), (2, 16)),
+             ((64, 8, 4, 0, 0), (8, 1)), ((1, 1, 1, 0, 0), (1, 2)), ((0, 0, 0, -3, -1), (1, 2)), ((5, 2, 3, 0, 0), (3, 2))]
+    for args, want in cases:
+        assert tuple(int(x) for x in run(host_probe, ["batchsizing"] + [str(a) for a in args])[0].split()) == want, args
+
+
+def test_cpu_list_parser(host_probe):
+    """parse_cpu_list (host layer): sysfs cpulists and MTGPU_CPU_WINDOW — numbers and ranges, order kept, duplicates
+    dropped; anything else is refused (the caller then does not pin)."""
+    def parse(t):
+        return run(host_probe, ["cpulist", t])[0]
+    assert parse("0-3") == "0,1,2,3" and parse("64-66,192-193") == "64,65,66,192,193"
+    assert parse("0,2,4") == "0,2,4" and parse(" 5 , 7-8\n") == "5,7,8" and parse("3,1-3") == "3,1,2"
+    assert parse("7") == "7" and run(host_probe, ["cpulist", ""]) in ([], [""])
+    for bad in ("a", "1-", "-3", "4-2", "1,,2", "1,", "1;2", "0x10", "1-2-3"):
+        assert parse(bad) == "invalid", bad
+
+
+def test_cpu_window_of_another_device_asked_from_a_pinned_worker(host_probe):
+    """cpu_window_for_device computes from the PROCESS's CPUs: a worker already pinned to device 0's window that is
+    the first to ask for device 1's must not get an empty window (round 4 used the calling thread's mask: on a
+    multi-GPU node every device but the first of a stream thread's came back empty and stayed so)."""
+    n = len(os.sched_getaffinity(0))
+    if n < 3:
+        pytest.skip("needs three CPUs")
+    out = run(host_probe, ["windowpinned"], {"MTGPU_CPU_WINDOW": "2"})[0].split()
+    got = dict(zip(out[0::2], (int(x) for x in out[1::2])))
+    assert got == {"allowed": n, "window0": 2, "window1": 2}
 
 
 def test_cpu_gate_and_cpu_budget(host_probe):
     """The host layer's CPU budget for the gate: cpu_budget() = the cgroup QUOTA (v2 cpu.max, v1 cfs quota, rounded
     up), else the CPUs the process may run on — deliberately not the reference's detect_cpu_limit(), which takes the
-    larger of quota and cpuset size (see test_stream_sizing_...) — and the CpuGate never lets more workers fill
+    larger of quota and cpuset size (see test_what_the_reference_would_choose_...) — and the CpuGate never lets more workers fill
     batches at once than it has tokens (0 tokens = no gate)."""
     def want_limit():
         try:
