@@ -22,6 +22,35 @@
  *    when the frame is reused (src/motion_scanner.cpp:347);
  *  - there is NO CPU fallback: if no gfx950 device is usable every compute entry
  *    point fails with MT_ERR_DEVICE.
+ *
+ * Memory the `*_device` entry points accept ("device pointer")
+ *  - memory of the context's device from hipMalloc / hipMallocAsync / hipMallocFromPoolAsync (what the bench
+ *    and the Python host use), or
+ *  - pinned host memory ALLOCATED BY THE DRIVER — hipHostMalloc, any flags — through its device address
+ *    (hipHostGetDevicePointer).  The pipe's zero-copy staging is exactly this: the kernel streams such memory over
+ *    PCIe and writes its one result byte per frame into it.
+ *  Every result byte is written once, by one lane, with a system-scope write-through store (no cache keeps the line),
+ *  so `d_flags` may share its lines with nothing the HOST writes while the call is in flight — give it lines of its
+ *  own (128-byte aligned) when it lives in host memory, as the pipe does.  Results in host memory are complete when
+ *  an event recorded behind the call on `stream` (hipEventReleaseToSystem) or a stream synchronisation has passed.
+ *  NOT supported, and not checked: host memory page-locked with hipHostRegister (a user-pointer mapping: its pages
+ *  are not pinned by the driver, the kernel driver re-validates the mapping when the OS touches them — the one wrong
+ *  result this library ever returned came from such staging), hipMallocManaged memory that is not
+ *  resident on the device, and memory of another device.
+ *
+ * Environment (read once, at mtgpu_create / at the first use; csrc/knobs.h)
+ *    production    MTGPU_CHECK_OFFSETS=1   device entry points verify frame_off first (one sync per call)
+ *                  MTGPU_PACK=scalar|avx2|avx512   copy-out loop of mtgpu_pack_records / the pipe (default: best the CPU has)
+ *                  MTGPU_ALIAS_DEVICES=N   present N logical devices on the GPUs that exist (rehearsals on small boxes)
+ *                  C++ host layer only: MTGPU_STAGING, MTGPU_BATCH_MB, MTGPU_CPU_TOKENS, MTGPU_CPU_WINDOW (mtgpu_host.hpp)
+ *    tests only    MTGPU_FORCE_FB=32|1|2|4|8|108, MTGPU_FORCE_BLOCK=512|1024, MTGPU_FORCE_SLICES, MTGPU_GROUP,
+ *                  MTGPU_ITEM_CHUNK, MTGPU_MERGE_LARGE_MIN (reach every kernel form on small inputs),
+ *                  MTGPU_INJECT_SUBMIT_FAIL / _GROW_FAIL / _COLLECT_FAIL / MTGPU_INJECT_ONCE (pipe error paths)
+ *    experiments   MTGPU_VARIANT, MTGPU_ALIGN, MTGPU_PREFETCH, MTGPU_DEFAULT_POOL, MTGPU_PIPE_STREAMS, MTGPU_PIPE_EAGER,
+ *                  MTGPU_EVENT_BLOCKING, MTGPU_MAX_TILE_KB, MTGPU_BAND_LDS_KB, MTGPU_MIN_LDS_KB, MTGPU_FORCE_CHUNK,
+ *                  MTGPU_PACK_NT, MTGPU_PACK_PREFETCH, MTGPU_FORCE_BLOCK=256: A/B switches whose losing side is
+ *                  documented; IGNORED by this library unless it was built with
+ *                  `make -C csrc experiments` (mtgpu_version() then ends in "+experiments")
  */
 #ifndef MTGPU_H
 #define MTGPU_H
@@ -164,7 +193,7 @@ int mtgpu_pack_records(const void *mv_bytes, uint64_t n_records, void *out8);
 /* The copy-out loop behind mtgpu_pack_records and mtgpu_batch_add_frame is chosen once per process from
  * what the host CPU supports (AVX-512BW: five 64-byte loads -> one full 64-byte line per 8 records; AVX2;
  * scalar), with non-temporal full-line stores into the staging the GPU reads next (csrc/pack_simd.cpp;
- * MTGPU_PACK=scalar|avx2|avx512 and MTGPU_PACK_NT=0|1 override).  mtgpu_pack_selected() reports the
+ * MTGPU_PACK=scalar|avx2|avx512 overrides).  mtgpu_pack_selected() reports the
  * choice; mtgpu_pack_records_with runs one given loop (tests, microbenchmarks): byte-identical output,
  * MT_ERR_UNSUPPORTED if this CPU cannot run it. */
 #define MT_PACK_SCALAR 1
@@ -310,11 +339,9 @@ typedef struct mtgpu_pipe_stats {
   int32_t layout;          /* MT_LAYOUT_* flags                                                    */
   uint64_t pin_us;         /* time spent page-locking staging (creation, first uses, growth)       */
   uint32_t pinned_batches; /* batches whose staging is pinned (the first at creation, the others   *
-                            * when mtgpu_pipe_acquire first hands them out; MTGPU_PIPE_EAGER=1:    *
-                            * all at creation)                                                     */
-  uint32_t hip_streams;    /* HIP streams OWNED by the pipe: 0 — batches run on the context's small stream   *
-                            * pool (MTGPU_PIPE_STREAMS, default 8; creating a stream costs ~3.5 ms,         *
-                            * serialised by the runtime) — or n_buffers with MTGPU_PIPE_STREAMS=0            */
+                            * when mtgpu_pipe_acquire first hands them out)                         */
+  uint32_t hip_streams;    /* HIP streams OWNED by the pipe: 0 — batches run on the context's pool of 8 streams      *
+                            * (creating a stream costs ~3.5 ms, serialised by the runtime)                    */
 } mtgpu_pipe_stats;
 int mtgpu_pipe_get_stats(mtgpu_pipe *pipe, mtgpu_pipe_stats *out);
 

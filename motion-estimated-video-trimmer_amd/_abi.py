@@ -140,7 +140,8 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    # MTGPU_LIBRARY: another build of the same ABI (developers: the experiments build, csrc/Makefile `experiments`)
+    p = path or os.environ.get("MTGPU_LIBRARY") or LIB_PATH
     # One HIP runtime per process: the PyTorch wheel bundles its own libamdhip64.so.7 /
     # libhsa-runtime64.so.1 (same SONAMEs as /opt/rocm).  If libmtgpu.so pulled in the
     # system copies first, a later `import torch` would find "No HIP GPUs".  Importing

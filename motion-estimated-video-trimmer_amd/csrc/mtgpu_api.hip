@@ -15,6 +15,7 @@
 
 #include "../../include/mtgpu.h"
 #include "api_internal.h"
+#include "knobs.h"
 #include "pack_simd.h"
 #include "merge_kernels.h"
 #include "scan_kernels.h"
@@ -137,10 +138,8 @@ size_t lds_need(int band_rows, int chunk_rows, int gw, int W, int fb, int *cnt_w
   return cw * 4u + (size_t)(chunk_rows + 2) * (size_t)W * 8u + 16u;
 }
 
-int env_int(const char *name, int dflt) {
-  const char *v = getenv(name);
-  return v ? atoi(v) : dflt;
-}
+using mtgpu::env_int;
+using mtgpu::exp_int;
 
 int make_plan(mtgpu_ctx *c, int lds_max, int cu_count) {
   const mt_scan_params &p = c->params;
@@ -179,7 +178,7 @@ int make_plan(mtgpu_ctx *c, int lds_max, int cu_count) {
   // MTGPU_MAX_TILE_KB (experiments): largest single tile; beyond it the grid is cut into row bands
   long single_max = lds_max;
   {
-    const int tkb = env_int("MTGPU_MAX_TILE_KB", 0);
+    const int tkb = exp_int("MTGPU_MAX_TILE_KB", 0);
     if (tkb > 0 && (long)tkb * 1024 < single_max) single_max = (long)tkb * 1024;
   }
   if (lds_need(R, R, k.gw, k.W, fb, nullptr) > (size_t)single_max) {
@@ -199,7 +198,7 @@ int make_plan(mtgpu_ctx *c, int lds_max, int cu_count) {
       // 2 bands 6.8 TB/s vs 4 bands 6.3-6.6), and every band less is one queue replay less on
       // vote-heavy input (pan: 5.1 vs 4.1 TB/s).  MTGPU_BAND_LDS_KB overrides the tile limit.
       long tile_max = (long)lds_max;
-      const int fkb = env_int("MTGPU_BAND_LDS_KB", 0);
+      const int fkb = exp_int("MTGPU_BAND_LDS_KB", 0);
       if (fkb > 0) tile_max = (long)fkb * 1024 < (long)lds_max ? (long)fkb * 1024 : (long)lds_max;
       const size_t per_row = ((size_t)k.gw * (size_t)fb + 7u) / 8u + mask_row;
       long r = 0;
@@ -231,7 +230,7 @@ int make_plan(mtgpu_ctx *c, int lds_max, int cu_count) {
       if (ch >= 8 && ch < chunk_rows) chunk_rows = (int)ch;
     }
   }
-  const int fchunk = env_int("MTGPU_FORCE_CHUNK", 0);         // experiments: smaller mask buffer
+  const int fchunk = exp_int("MTGPU_FORCE_CHUNK", 0);         // experiments: smaller mask buffer
   if (fchunk >= 1 && fchunk < chunk_rows) { chunk_rows = fchunk; c->wide_chunk_rows = fchunk; c->wide_lds_bytes = (int)lds_need(band_rows, fchunk, k.gw, k.W, fb, nullptr); }
   k.fb = fb;
   k.band_rows = band_rows;
@@ -243,8 +242,12 @@ int make_plan(mtgpu_ctx *c, int lds_max, int cu_count) {
   // 4 workgroups/CU (measured +2.5 % over 256 on 1080p); tiles above 48 KB run 1-2
   // workgroups/CU and take 16 waves each.
   int block = lds <= 48u * 1024u ? 512 : 1024;
+  // MTGPU_FORCE_BLOCK (tests): 512 | 1024.  The default build instantiates what the planner can choose plus that
+  // switch: 512- and 1024-thread workgroups for single tiles, 1024 for banded plans (their tiles always exceed 48 KB);
+  // 256-thread workgroups and 512-thread banded ones exist only in the experiments build.
   const int fblock = env_int("MTGPU_FORCE_BLOCK", 0);
-  if (fblock == 256 || fblock == 512 || fblock == 1024) block = fblock;
+  if (fblock == 512 || fblock == 1024 || (mtgpu::kExperiments && fblock == 256)) block = fblock;
+  if (!mtgpu::kExperiments && k.bands > 1) block = 1024;
   c->plan.block_threads = block;
   c->plan.bands = k.bands;
   c->plan.band_rows = k.band_rows;
@@ -253,19 +256,19 @@ int make_plan(mtgpu_ctx *c, int lds_max, int cu_count) {
   c->plan.device = c->logical_device;
   c->plan.cu_count = cu_count;
   c->plan.chunk_rows = chunk_rows;
-  c->variant = env_int("MTGPU_VARIANT", 0);
+  c->variant = exp_int("MTGPU_VARIANT", 0);
   {
     const int fs = env_int("MTGPU_FORCE_SLICES", 0);
     c->slices_request = (fs == 1 || fs == 2 || fs == 4 || fs == 8) ? fs : 0;
   }
   k.slices = 1;
   k.group = 1;
-  k.align_lines = env_int("MTGPU_ALIGN", 1) != 0 ? 1 : 0;     // experiments: 0 = streams start wherever the frame starts
-  k.prefetch = env_int("MTGPU_PREFETCH", 1) != 0 ? 1 : 0;      // experiments: 0 switches the next-frame prefetch off
+  k.align_lines = exp_int("MTGPU_ALIGN", 1) != 0 ? 1 : 0;     // experiments: 0 = streams start wherever the frame starts
+  k.prefetch = exp_int("MTGPU_PREFETCH", 1) != 0 ? 1 : 0;      // experiments: 0 switches the next-frame prefetch off
   c->group_request = env_int("MTGPU_GROUP", 0);
-  c->min_lds_kb = env_int("MTGPU_MIN_LDS_KB", 0);
+  c->min_lds_kb = exp_int("MTGPU_MIN_LDS_KB", 0);
   c->check_offsets = env_int("MTGPU_CHECK_OFFSETS", 0) != 0;
-  c->n_pipe_streams = std::min(std::max(env_int("MTGPU_PIPE_STREAMS", 8), 0), (int)mtgpu_ctx::kMaxPipeStreams);
+  c->n_pipe_streams = std::min(std::max(exp_int("MTGPU_PIPE_STREAMS", 8), 0), (int)mtgpu_ctx::kMaxPipeStreams);
   c->item_chunk = env_int("MTGPU_ITEM_CHUNK", 0);
   if (c->item_chunk < 0) c->item_chunk = 0;
   {
@@ -445,7 +448,9 @@ extern "C" int mtgpu_debug_set_phase_times(void *p) {      // developer build on
 
 extern "C" {
 
-const char *mtgpu_version(void) { return "mtgpu 0.4 (gfx950 MV scan + segment merge)"; }
+const char *mtgpu_version(void) {
+  return mtgpu::kExperiments ? "mtgpu 0.5 (gfx950 MV scan + segment merge) +experiments" : "mtgpu 0.5 (gfx950 MV scan + segment merge)";
+}
 
 const char *mtgpu_last_error(void) { return g_err; }
 
@@ -523,7 +528,7 @@ int mtgpu_create(const mt_scan_params *params, int device, mtgpu_ctx **out) {
   if (rc != MT_OK) { delete c; return rc; }
   e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete c; return hip_fail(e, "hipStreamCreate"); }
-  if (env_int("MTGPU_DEFAULT_POOL", 0) == 0) {
+  if (exp_int("MTGPU_DEFAULT_POOL", 0) == 0) {
     hipMemPoolProps props;
     std::memset(&props, 0, sizeof props);
     props.allocType = hipMemAllocationTypePinned;

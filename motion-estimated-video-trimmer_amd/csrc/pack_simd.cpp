@@ -23,8 +23,10 @@
 
 #include <cstdint>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 
+#include "knobs.h"
 #include "pack_simd.h"
 
 namespace mtgpu {
@@ -153,8 +155,8 @@ const Choice &choice() {          // read once; thread-safe (function-local stat
                        : !std::strcmp(e, "avx512") ? MT_PACK_AVX512 : -1;
       if (want > 0 && cpu_has(want)) ch.impl = want;     // a loop this CPU cannot run is never selected
     }
-    if (const char *e = std::getenv("MTGPU_PACK_NT")) ch.nt = std::atoi(e) != 0;
-    if (const char *e = std::getenv("MTGPU_PACK_PREFETCH")) ch.prefetch = (uint64_t)std::strtoull(e, nullptr, 10);
+    ch.nt = exp_int("MTGPU_PACK_NT", 1) != 0;                                  // experiments build only
+    ch.prefetch = (uint64_t)std::max(0, exp_int("MTGPU_PACK_PREFETCH", 0));    // experiments build only
     return ch;
   }();
   return c;

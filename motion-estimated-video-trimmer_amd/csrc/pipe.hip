@@ -35,11 +35,17 @@
 #include <vector>
 
 #include "api_internal.h"
+#include "knobs.h"
 #include "pack_simd.h"
 
 struct mtgpu_batch {
   // pinned host staging: ONE block per batch,
-  //   [off (cap_frames+1) x 8 | sd cap_frames | pad to 64 | records | pad to 64 | pts | tags | flags]
+  //   [off (cap_frames+1) x 8 | sd cap_frames | pad to 64 | records | pad to 128 | pts | tags | pad to 128 | flags | pad to 128]
+  // The flag bytes — the only part of the block the DEVICE writes — own their 128-byte lines: no line holds both
+  // bytes the host stored (pts, tags, records) and bytes the device stores.  x86 keeps such a shared line coherent
+  // for snooped PCIe writes, so this is not a fix of a known fault; it removes the one place where the block's
+  // correctness leaned on how a partial device write merges into a line the host holds modified (round 4's
+  // unexplained wrong flag with hipHostRegister'ed staging).
   // so a batch goes up with a single H2D copy of its head (without zero-copy): with many decoder threads
   // submitting concurrently the runtime's per-call cost, not PCIe, is what a submit pays for.  The block is
   // pinned on the batch's FIRST use (mtgpu_pipe_acquire), not at pipe creation: page-locking costs ~0.2 ms per
@@ -87,7 +93,8 @@ struct mtgpu_pipe {
   long collects = 0;
   long submits = 0;
   bool inject_grow_fail = false; // MTGPU_INJECT_GROW_FAIL=1 (tests): growing a batch for an oversize frame fails
-  uint64_t pin_us = 0;           // time spent page-locking staging blocks (creation + first uses + growth)
+  std::atomic<uint64_t> pin_us{0};   // time spent page-locking staging blocks (creation + first uses + growth); add_frame
+                                     // grows a batch without the pipe lock, get_stats reads under it: atomic
   std::vector<mtgpu_batch *> bufs;
   std::deque<mtgpu_batch *> inflight;
   std::mutex mu;
@@ -112,12 +119,15 @@ size_t stage_bytes_for(uint32_t cap_frames, uint64_t records, int rec_bytes, siz
   const size_t nf = (size_t)cap_frames;
   const size_t hdr = (sizeof(uint64_t) * (nf + 1) + (nf + 1) + 63u) & ~(size_t)63u;
   if (hdr_out) *hdr_out = hdr;
-  return (hdr + (size_t)records * (size_t)rec_bytes + 64 + 63u) & ~(size_t)63u;
+  return (hdr + (size_t)records * (size_t)rec_bytes + 64 + 127u) & ~(size_t)127u;
 }
 
-size_t aux_bytes_for(uint32_t cap_frames) {          // [pts (nf+1) x 8 | tags (nf+1) x 8 | flags nf+1], 64-byte aligned
+// [pts (nf+1) x 8 | tags (nf+1) x 8 | pad to 128 | flags nf+1 | pad to 128]; *flags_off = offset of the flags
+size_t aux_bytes_for(uint32_t cap_frames, size_t *flags_off = nullptr) {
   const size_t nf = (size_t)cap_frames + 1;
-  return (nf * (sizeof(double) + sizeof(uint64_t)) + nf + 63u) & ~(size_t)63u;
+  const size_t fo = (nf * (sizeof(double) + sizeof(uint64_t)) + 127u) & ~(size_t)127u;
+  if (flags_off) *flags_off = fo;
+  return fo + ((nf + 127u) & ~(size_t)127u);
 }
 
 #define PIPE_TRY(expr)                                               \
@@ -134,8 +144,12 @@ int pin_block(mtgpu_batch *b, uint64_t records, bool inject_failure = false) {
   unsigned char *h_new = nullptr, *d_new = nullptr, *dev_view = nullptr;
   size_t hdr = 0;
   const size_t sbytes = stage_bytes_for(b->cap_frames, records, b->rec_bytes, &hdr);
-  const size_t bytes = sbytes + aux_bytes_for(b->cap_frames);
+  size_t flags_off = 0;
+  const size_t bytes = sbytes + aux_bytes_for(b->cap_frames, &flags_off);
   const size_t nf = (size_t)b->cap_frames + 1;
+  // Driver-allocated pinned memory (hipHostMallocDefault: coherent, mapped into the device), on purpose — see
+  // include/mtgpu.h "Memory the device entry points accept" and DESIGN.md §5a for why hipHostRegister'ed user
+  // memory is not used although it page-locks five times faster.
   PIPE_TRY(hipHostMalloc(reinterpret_cast<void **>(&h_new), bytes, hipHostMallocDefault));
   if (inject_failure) { rc = fail(MT_ERR_NOMEM, "injected allocation failure (MTGPU_INJECT_GROW_FAIL)"); goto bad; }
   if (b->zero_copy) {
@@ -158,11 +172,11 @@ int pin_block(mtgpu_batch *b, uint64_t records, bool inject_failure = false) {
   b->h_mv = h_new + hdr;
   b->h_pts = reinterpret_cast<double *>(h_new + sbytes);
   b->h_tag = reinterpret_cast<uint64_t *>(h_new + sbytes + nf * sizeof(double));
-  b->h_flags = h_new + sbytes + nf * (sizeof(double) + sizeof(uint64_t));
+  b->h_flags = h_new + sbytes + flags_off;
   b->d_off = reinterpret_cast<uint64_t *>(dev_view);
   b->d_sd = dev_view + sizeof(uint64_t) * nf;
   b->d_mv = dev_view + hdr;
-  b->d_flags = dev_view + sbytes + nf * (sizeof(double) + sizeof(uint64_t));
+  b->d_flags = dev_view + sbytes + flags_off;
   b->h_off[0] = 0;
   b->cap_records = records;
   return MT_OK;
@@ -242,8 +256,8 @@ int mtgpu_pipe_create_layout(mtgpu_ctx *ctx, uint64_t max_records_per_batch, uin
   p->ctx = ctx;
   p->rec_bytes = (layout & MT_LAYOUT_AOS40) ? MT_MV_BYTES : MT_COMPACT_BYTES;
   p->zero_copy = (layout & MT_LAYOUT_ZERO_COPY) != 0;
-  if (const char *v = std::getenv("MTGPU_EVENT_BLOCKING")) p->blocking_events = std::atol(v) != 0;
-  if (const char *v = std::getenv("MTGPU_PIPE_EAGER")) p->eager_pin = std::atol(v) != 0;
+  p->blocking_events = mtgpu::exp_int("MTGPU_EVENT_BLOCKING", 0) != 0;     // experiments build only
+  p->eager_pin = mtgpu::exp_int("MTGPU_PIPE_EAGER", 0) != 0;                // experiments build only
   if (const char *v = std::getenv("MTGPU_INJECT_SUBMIT_FAIL")) p->inject_submit_fail = std::atol(v);
   if (const char *v = std::getenv("MTGPU_INJECT_GROW_FAIL")) p->inject_grow_fail = std::atol(v) != 0;
   if (const char *v = std::getenv("MTGPU_INJECT_COLLECT_FAIL")) p->inject_collect_fail = std::atol(v);
@@ -426,7 +440,7 @@ int mtgpu_pipe_get_stats(mtgpu_pipe *p, mtgpu_pipe_stats *out) {
       if (!b->zero_copy) out->device_bytes += b->block_bytes;
       out->pinned_batches += 1;
     }
-  out->pin_us = p->pin_us;
+  out->pin_us = p->pin_us.load();
   for (const mtgpu_batch *b : p->bufs) out->hip_streams += b->own_stream ? 1u : 0u;
   out->submits = (uint64_t)p->submits;
   out->n_buffers = (uint32_t)p->bufs.size();

@@ -50,6 +50,7 @@
 
 #include <atomic>
 
+#include "knobs.h"
 #include "scan_kernels.h"
 
 namespace mtgpu {
@@ -279,6 +280,15 @@ __device__ __forceinline__ unsigned int combine_words(unsigned int a, unsigned i
   }
 }
 
+// The one result byte of a frame.  Written with a SYSTEM-scope store (global_store_byte ... sc0 sc1: write-through
+// past the XCD's L2, byte-masked): `flags` may be pinned host memory that the kernel writes over PCIe (the pipe's
+// zero-copy staging) next to bytes other workgroups — on other XCDs — write into the same line at other times, so
+// no cache on the way may hold the line and merge it back later.  On device memory the store costs the same
+// (one byte per frame) and the line simply is not kept in L2.
+__device__ __forceinline__ void store_flag(unsigned char *flags, unsigned int f, unsigned char v) {
+  __hip_atomic_store(&flags[f], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // Where a spilling workgroup (SPILL) keeps the votes later bands need.
 struct SpillQ {
   unsigned int *q;        // this frame's queue: one slot per record of the frame
@@ -389,7 +399,7 @@ __device__ __forceinline__ void scan_item(
   r0 = r0 < r1 ? r0 : r1;
   const bool sd = has_sd ? (has_sd[f] != 0) : (r1 > r0);
   if (!sd) {                                   // :219-221 — no side data: false
-    if (slice == 0 && tid == 0) flags[f] = 0;
+    if (slice == 0 && tid == 0) store_flag(flags, f, 0);
     ns.have = false;                           // (never set for such a frame today: a step is only pre-issued for frames with side data)
     return;
   }
@@ -754,7 +764,7 @@ __device__ __forceinline__ void scan_item(
   if (local) atomicAdd(total, local);
   __syncthreads();
 
-  if (tid == 0) flags[f] = (*total >= k.clust_need) ? 1 : 0;
+  if (tid == 0) store_flag(flags, f, (*total >= k.clust_need) ? 1 : 0);
   PT_FLUSH();
 }
 
@@ -870,8 +880,9 @@ static hipError_t launch_one(const ScanLaunch &L) {
   return hipSuccess;
 }
 
+#ifdef MTGPU_EXPERIMENTS
 // Experiment variants of the ADD32 kernel on 40-byte records (MTGPU_VARIANT): bit0 UNROLL 8,
-// bit1 dwordx4 loads, bit2 no nt hint, bit3 software-pipelined loop.
+// bit1 dwordx4 loads, bit2 no nt hint, bit3 software-pipelined loop.  Experiments build only.
 template <int BLOCK>
 static hipError_t launch_variant(const ScanLaunch &L) {
   switch (L.variant & 15) {
@@ -883,6 +894,7 @@ static hipError_t launch_variant(const ScanLaunch &L) {
     default: return launch_one<BLOCK, 32, MODE_ADD32, 40, false>(L);
   }
 }
+#endif
 
 template <int BLOCK, int REC, bool SPILL>
 static hipError_t launch_form(const ScanLaunch &L) {
@@ -898,14 +910,26 @@ static hipError_t launch_form(const ScanLaunch &L) {
   }
 }
 
+// Default build: the instantiations a plan can select — single tiles with 512 or 1024 threads, banded plans with
+// 1024 (make_plan, mtgpu_api.hip) — 36 kernels.  The experiments build adds 256-thread workgroups, 512-thread
+// banded ones and the MTGPU_VARIANT load variants (117 kernels, three times the compile time and code size).
 template <int BLOCK>
 static hipError_t launch_block(const ScanLaunch &L) {
-  const int key = L.k.mode * 100 + L.k.fb;
   const bool spill = L.k.bands > 1;
+#ifdef MTGPU_EXPERIMENTS
+  const int key = L.k.mode * 100 + L.k.fb;
   if (L.rec_bytes == 40 && !spill && key == MODE_ADD32 * 100 + 32 && (L.variant & 15) != 0 && BLOCK != 1024)
     return launch_variant<BLOCK>(L);
-  if (L.rec_bytes == 8) return spill ? launch_form<BLOCK, 8, true>(L) : launch_form<BLOCK, 8, false>(L);
-  return spill ? launch_form<BLOCK, 40, true>(L) : launch_form<BLOCK, 40, false>(L);
+  constexpr bool kSpillHere = true;
+#else
+  constexpr bool kSpillHere = BLOCK == 1024;
+#endif
+  if constexpr (kSpillHere) {
+    if (spill) return L.rec_bytes == 8 ? launch_form<BLOCK, 8, true>(L) : launch_form<BLOCK, 40, true>(L);
+  } else {
+    if (spill) return hipErrorInvalidValue;
+  }
+  return L.rec_bytes == 8 ? launch_form<BLOCK, 8, false>(L) : launch_form<BLOCK, 40, false>(L);
 }
 
 #ifdef MTGPU_PHASE_TIMES
@@ -926,7 +950,9 @@ hipError_t launch_scan(const ScanLaunch &L) {
     if (e != hipSuccess) return e;
   }
   switch (L.block) {
+#ifdef MTGPU_EXPERIMENTS
     case 256: e = launch_block<256>(L); break;
+#endif
     case 512: e = launch_block<512>(L); break;
     case 1024: e = launch_block<1024>(L); break;
     default: return hipErrorInvalidValue;

@@ -55,3 +55,11 @@ def gpu_scanner_factory():
     yield make
     for s in made:
         s.close()
+
+
+def experiments_build():
+    """True when the loaded libmtgpu is the A/B build (csrc/Makefile `experiments`, MTGPU_LIBRARY): only there are
+    the exp_int() knobs of csrc/knobs.h (MTGPU_ALIGN, MTGPU_PREFETCH, MTGPU_PIPE_EAGER, MTGPU_PIPE_STREAMS, ...)
+    read at all.  The default build ignores them, so the knob-off halves of a few tests run only on that build."""
+    import mvtrim_amd as m
+    return b"+experiments" in m.load_library().mtgpu_version()

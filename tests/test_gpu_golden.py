@@ -23,6 +23,7 @@ from mvtrim_amd import dist as mdist
 from mvtrim_amd import synth
 
 import oracle_binding as ob
+from conftest import experiments_build
 from golden_cases import (build_mvs, id_of, load_filter_cases, load_hand_cases, load_merge_cases,
                           load_survey_segments, merge_case_ts)
 
@@ -871,6 +872,8 @@ def test_pipe_pins_staging_on_first_use(gpu_scanner_factory, monkeypatch, layout
     st = stats(pipe)
     assert 2 <= st.pinned_batches <= 3 and st.pinned_bytes == st.pinned_batches * one
     pipe.close()
+    if not experiments_build():                  # MTGPU_PIPE_EAGER is an A/B knob: read by the experiments build only
+        return
     monkeypatch.setenv("MTGPU_PIPE_EAGER", "1")
     pipe = m.ScanPipe(s, 8160 * 4, 4, 3, layout=layout)
     st = stats(pipe)
@@ -900,7 +903,7 @@ def test_pipe_batches_run_on_the_contexts_stream_pool(gpu_scanner_factory, monke
         st = m._abi.PipeStatsC()
         m._abi.check(lib.mtgpu_pipe_get_stats(pipe._pipe, C.byref(st)))
         return st
-    for pooled in (True, False):
+    for pooled in ((True, False) if experiments_build() else (True,)):     # MTGPU_PIPE_STREAMS: experiments build only
         if not pooled:
             monkeypatch.setenv("MTGPU_PIPE_STREAMS", "0")
         s = gpu_scanner_factory(p)

@@ -11,6 +11,7 @@ import mvtrim_amd as m
 from mvtrim_amd import synth
 
 import oracle_binding as ob
+from conftest import experiments_build
 
 pytestmark = pytest.mark.gpu
 
@@ -989,7 +990,7 @@ def test_scan_line_aligned_streams(gpu_scanner_factory, monkeypatch):
     rec = m.pack_records(b.mv)
     d_rec = torch.from_numpy(rec.view(np.uint8).reshape(-1).copy()).cuda()
     d_off = torch.from_numpy(b.frame_off.astype(np.int64)).cuda()
-    for align in ("1", "0"):
+    for align in (("1", "0") if experiments_build() else ("1",)):     # MTGPU_ALIGN=0: experiments build only
         for fb in (None, 2, 8):                                     # 32-bit single tile, packed, banded (spill queue)
             monkeypatch.setenv("MTGPU_ALIGN", align)
             s = gpu_scanner_factory(m.ScanParams.from_config(1920, 1080, vectors_needed=2, clusters_needed=1), force_fb=fb)
@@ -1051,6 +1052,8 @@ def test_compact_next_frame_prefetch(gpu_scanner_factory, monkeypatch, grid):
         if kw["vectors_needed"] == 2:
             assert want.tolist() == [1 if k == "A" else 0 for k in kinds]
         for g, pf in ((2, 1), (3, 1), (4, 1), (8, 1), (25, 1), (64, 1), (4, 0), (1, 1)):
+            if pf == 0 and not experiments_build():           # MTGPU_PREFETCH=0 / MTGPU_ALIGN=0: experiments build only
+                continue
             monkeypatch.setenv("MTGPU_GROUP", str(g))
             monkeypatch.setenv("MTGPU_PREFETCH", str(pf))
             monkeypatch.setenv("MTGPU_ALIGN", str(pf))            # without the prefetch also without the line alignment
@@ -1404,3 +1407,43 @@ def test_throwing_decoder_fails_its_video_and_returns_the_cpu_token(tmp_path):
     assert out.startswith("rc 1 ") and "tokens 1 " in out and "decoder lost the stream at frame 777" in out, out
     out = subprocess.run([exe, "3", "-1"], env=env, capture_output=True, text=True, timeout=120).stdout
     assert out.startswith("rc 0 motion 700 tokens 1 "), out          # frames 100..199, 300..399, ...: 7 x 100 moving frames
+
+
+def test_recorded_wrong_flag_configuration_through_every_path(gpu_scanner_factory, monkeypatch):
+    """The one configuration in which this library ever returned a wrong answer (round 4, with staging that was
+    page-locked by hipHostRegister: profiles/r04_soak_mismatch_with_registered_staging.txt, reconstructed by
+    tests/soak_replay.py) through all three paths — 40-byte records, device-resident compact records (the soak had NOT
+    run that path in the failing iteration, so the REC 8 / 8-bit CAS / two-frames-per-workgroup kernel was only ever
+    seen through the pipe), and the zero-copy pipe with the recorded geometry, a fresh pipe each time so that frame 33
+    again sits in the first use of a freshly pinned block."""
+    import torch
+    from soak_replay import replay
+    head, tail, plan, p = replay(10242, 70, pipe_every=5)
+    mv, off, sd = tail["mv"], tail["off"], tail["sd"]
+    want = ob.scan_frames(p, mv, off, sd)
+    assert want[33] == 1 and want[32] == 1
+    for k_, v_ in head["knobs"].items():
+        if v_:
+            monkeypatch.setenv(k_, v_)
+    s = gpu_scanner_factory(p, force_fb=head["force_fb"])
+    for k_ in head["knobs"]:
+        monkeypatch.delenv(k_, raising=False)
+    s.set_slices(tail["slices"])
+    assert s.plan["counter_mode"] == 2 and s.plan["counter_bits"] == 8
+    rec = m.pack_records(mv)
+    d_rec = torch.from_numpy(rec.view(np.uint8).reshape(-1).copy()).cuda()
+    d_off = torch.from_numpy(off.astype(np.int64)).cuda()
+    d_sd = torch.from_numpy(sd).cuda()
+    for rep in range(3):
+        assert np.array_equal(s.check_frames(m.FrameBatch(mv, off, None, sd)), want), rep
+        assert np.array_equal(s.check_frames_device_compact(d_rec, d_off, d_sd).cpu().numpy(), want), ("compact", rep)
+        # the second half alone, as the pipe's second batch shipped it (frame 33 = item 1 of the launch)
+        got = s.check_frames_device_compact(d_rec, d_off[32:].contiguous(), d_sd[32:].contiguous()).cpu().numpy()
+        assert np.array_equal(got, want[32:]), ("compact, frames 32..63", rep)
+        pipe = m.ScanPipe(s, *tail["pipe"])
+        for f in range(tail["n_frames"]):
+            fr = mv[int(off[f]):int(off[f + 1])]
+            pipe.feed(fr if sd[f] else None, float(f), tag=f)
+        out = pipe.drain()
+        pipe.close()
+        assert [fl for _, fl, _ in out] == want.tolist(), ("pipe", rep)

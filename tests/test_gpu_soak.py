@@ -11,6 +11,7 @@ import mvtrim_amd as m
 from mvtrim_amd import synth
 
 import oracle_binding as ob
+from soak_replay import draw_head, draw_tail
 
 pytestmark = pytest.mark.gpu
 
@@ -19,7 +20,6 @@ def test_soak_random_parity(gpu_scanner_factory):
     budget = float(os.environ.get("MTGPU_SOAK_SECONDS", "4"))
     seed = int(os.environ.get("MTGPU_SOAK_SEED", "12345"))
     rng = np.random.RandomState(seed)
-    forms = [None, None, 1, 2, 4, 8, 108, 32]
     t_end = time.time() + budget
     it = done = 0
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -31,36 +31,23 @@ def test_soak_random_parity(gpu_scanner_factory):
             last_note = time.time()
             with open(os.path.join(prog_dir, "soak_progress.log"), "a") as fh:
                 fh.write(f"{time.strftime('%H:%M:%S')} seed {seed}: {done} configurations ok\n")
-        sh = int(rng.randint(1 if it % 7 == 0 else 2, 6))        # shift 1: grids up to ~1900x1100 -> row bands
-        w, h = int(rng.randint(64, 3900)), int(rng.randint(64, 2200))
-        kw = dict(mv_threshold_sq=float(rng.choice([16.0, 4.0, 0.0, 9.5])), block_size=1 << sh, block_shift=sh,
-                  vectors_needed=int(rng.choice([1, 1, 2, 2, 3, 4, 6, 12, 255])),
-                  clusters_needed=int(rng.choice([1, 2, 2, 3, 10])),
-                  vertical_mask=float(rng.choice([0.0, 0.05, 0.2])))
+        head = draw_head(rng, it)
+        w, h, kw, knobs = head["w"], head["h"], head["kw"], head["knobs"]
         p = ob.params_from_config(w, h, **kw)
-        # frames per workgroup (next-frame prefetch on compact records), line alignment: knobs read at create time
-        knobs = {"MTGPU_GROUP": rng.choice(["", "", "2", "3", "8"]), "MTGPU_PREFETCH": rng.choice(["", "", "0"]),
-                 "MTGPU_ALIGN": rng.choice(["", "", "0"])}
         for k_, v_ in knobs.items():
             if v_:
                 os.environ[k_] = str(v_)
         try:
-            s = gpu_scanner_factory(p, force_fb=forms[it % len(forms)])
+            s = gpu_scanner_factory(p, force_fb=head["force_fb"])
         except m.MtgpuError as e:
             assert e.code == 2
             continue
         finally:
             for k_ in knobs:
                 os.environ.pop(k_, None)
-        s.set_slices(int(rng.choice([0, 1, 2, 4, 8])))
-        n_frames = int(rng.choice([3, 17, 64, 300]))
-        mv, off, sd = synth.random_frames(rng, n_frames, int(rng.choice([200, 3000, 20000, 20000 if n_frames > 64 else 60000])), w, h,
-                                          hot=float(rng.choice([0.05, 0.5, 0.95])))
-        if it % 2 == 0 and len(mv):                   # runs: every record repeated 1..6 times back to back (a block's
-            r = rng.randint(1, 7, size=len(mv))         # several vectors) — the run-aggregated vote path of packed forms
-            csum = np.concatenate([[0], np.cumsum(r)])
-            off = csum[off.astype(np.int64)].astype(np.uint64)
-            mv = np.repeat(mv, r)
+        tail = draw_tail(rng, it, head)
+        s.set_slices(tail["slices"])
+        n_frames, mv, off, sd = tail["n_frames"], tail["mv"], tail["off"], tail["sd"]
         want = ob.scan_frames(p, mv, off, sd, nthreads=8)
         for _ in range(2):                              # twice: warm caches, reused workspaces
             got = s.check_frames(m.FrameBatch(mv, off, None, sd))
@@ -75,7 +62,7 @@ def test_soak_random_parity(gpu_scanner_factory):
             assert np.array_equal(got, want), ("compact", seed, it, w, h, kw, s.plan, knobs)
         if it % 2 == 0:                                 # the pinned pipe (zero-copy compact staging): every other configuration
                                                         # since round 4 — staging reuse is where a visibility fault would show
-            pipe = m.ScanPipe(s, int(rng.choice([500, 5000, 50000])), int(rng.choice([1, 4, 32])), int(rng.choice([1, 2, 3])))
+            pipe = m.ScanPipe(s, *tail["pipe"])
             for f in range(n_frames):
                 fr = mv[int(off[f]):int(off[f + 1])]
                 pipe.feed(fr if sd[f] else None, float(f), tag=f)

@@ -169,3 +169,32 @@ def test_launch_planner_known_answers_and_invariants(monkeypatch):
         bad = m.ScanParams.from_config(1920, 1080)
         bad.grid_w = 0
         m.plan_preview(bad)
+
+
+def test_replay_of_the_recorded_wrong_flag_configuration():
+    """profiles/r04_soak_mismatch_with_registered_staging.txt (seed 10242, iteration 70, frame 33: the zero-copy pipe on
+    hipHostRegister'ed staging returned 0 where the oracle says 1) replayed on the CPU from the soak's own random stream
+    (tests/soak_replay.py; the soak fed the pipe every 5th iteration then).  What the record can and cannot mean is
+    read off here instead of re-running the soak:
+      - the reconstruction is the recorded configuration (949 x 146, shift 4, T 4.0, 8-bit CAS fields forced);
+      - two batches through two staging blocks, no re-pin: frame 33 sat in the FIRST use of a freshly pinned block,
+        so neither staging reuse, nor a recycled address, nor the grow path can be the cause;
+      - frame 33 was position 1 of its batch: flag byte 1, written by the same lane that wrote byte 0 (two frames per
+        workgroup) — and byte 0 (frame 32) arrived;
+      - its answer is not marginal: 42 centre cells against a need of 2, no single lost vote flips it, a frame whose
+        records all read as zeros would — the fault was wholesale (the result byte, or the frame's whole record range)."""
+    import oracle_binding as ob
+    from soak_replay import pipe_batches, replay
+    head, tail, plan, p = replay(10242, 70, pipe_every=5)
+    assert (head["w"], head["h"], head["kw"]["block_shift"], head["kw"]["mv_threshold_sq"]) == (949, 146, 4, 4.0)
+    assert head["force_fb"] == 108 and plan["counter_mode"] == 2 and plan["bands"] == 1 and head["knobs"]["MTGPU_GROUP"] == "2"
+    assert tail["pipe"] == (50000, 32, 2) and tail["n_frames"] == 64
+    batches, grows = pipe_batches(tail["off"], tail["sd"], *tail["pipe"])
+    assert grows == [] and [(slot, fr[0], fr[-1]) for slot, fr, _ in batches] == [(0, 0, 31), (1, 32, 63)]
+    mv, off, sd = tail["mv"], tail["off"], tail["sd"]
+    fr = mv[int(off[33]):int(off[34])]
+    flag, centres, _ = ob.check_frame(p, fr, True, count_centres=True)
+    assert (flag, centres) == (1, 42) and p.clusters_needed == 2
+    assert ob.check_frame(p, mv[int(off[32]):int(off[33])], True) == 1
+    assert all(ob.check_frame(p, np.delete(fr, i), True) == 1 for i in range(0, len(fr), 7))
+    assert ob.check_frame(p, np.zeros_like(fr), True) == 0
