@@ -294,13 +294,33 @@ struct SpillQ {
   unsigned int *q;        // this frame's queue: one slot per record of the frame
   unsigned int *tail;     // entries so far (LDS)
   int q_lo;               // first grid row a later band tracks (band 0's last centre row)
+  __amdgpu_buffer_rsrc_t rsrc;   // the same queue as a raw buffer (4 bytes per record of the frame): a store beyond it is
+                                 // DROPPED by the hardware.  Byte offsets are 32-bit: DROP kernels are launched only for
+                                 // batches of fewer than 2^30 records (launch_form), so that every frame fits
 };
+
+// What one lane appends to the frame's queue for one record: byte offset of its slot (NO_SLOT: nothing) and the entry.
+struct QEntry { unsigned int off, e; };
+constexpr unsigned int NO_SLOT = 0xffffffffu;
+
+// Queue stores.  PLAIN: a store under a branch per record (lanes without an entry skip it).  With such branches
+// between the loads of a step the compiler can no longer count which vector-memory operations are pending (a store may
+// or may not have been issued), takes the smaller count and so makes the wave wait for the ACK of the stores it just
+// issued before it may use the next load of the same step — a store round trip per step, serialised with the loads.
+// DROP: every lane stores, lanes without an entry at an offset beyond the buffer, where the hardware discards the
+// store: no branch, exact counts, and a wave never waits for a queue store (only before the replay, vmcnt(0)).
+template <bool DROP>
+__device__ __forceinline__ void queue_store(const SpillQ &sq, const QEntry qe) {
+  if constexpr (DROP) __builtin_amdgcn_raw_buffer_store_b32(qe.e, sq.rsrc, qe.off, 0, 0);
+  else if (qe.off != NO_SLOT) sq.q[qe.off >> 2] = qe.e;
+}
 
 // Threshold + cell mapping + vote for one record (src/motion_scanner.cpp:246-267).
 // [t0,t1) = grid rows this tile tracks.
 template <int FB, int MODE, bool SPILL>
-__device__ __forceinline__ void vote(const MvFields m, const ScanK &k, int t0, int t1,
-                                     unsigned int *cnt, const SpillQ &sq) {
+__device__ __forceinline__ QEntry vote(const MvFields m, const ScanK &k, int t0, int t1,
+                                       unsigned int *cnt, const SpillQ &sq) {
+  QEntry qe = {NO_SLOT, 0u};
   const unsigned int dx = (unsigned int)(m.dst_x - m.src_x);   // |dx| <= 65535
   const unsigned int dy = (unsigned int)(m.dst_y - m.src_y);
   // dx*dx < 2^32 exactly; the sum needs 34 bits.  (The compiler proves the operands fit 17 bits and already
@@ -316,6 +336,7 @@ __device__ __forceinline__ void vote(const MvFields m, const ScanK &k, int t0, i
   if constexpr (!SPILL && (MODE == MODE_ADD32 || (MODE == MODE_UNARY && FB == 1))) {
     // fire-and-forget LDS atomics (32-bit add, 1-bit or): a single tile tracks every analysed row
     if (in) bump<FB, MODE>(cnt, (unsigned int)((gy - t0) * k.gw + gx), k.vec_need);
+    return qe;
   } else {
     // Returning LDS atomics (thermometer / CAS fields) and the spill queue: RUNS of records that one wave
     // instruction maps to the same cell — codecs export several vectors per block (two prediction directions,
@@ -323,7 +344,7 @@ __device__ __forceinline__ void vote(const MvFields m, const ScanK &k, int t0, i
     // records of a block otherwise queue up on ONE LDS word four times over (8 cells of a 4-bit form share a
     // word), and each would append its own queue entry.  A wave instruction without a voter costs one ballot.
     const unsigned long long any = __ballot(in);
-    if (any == 0ull) return;
+    if (any == 0ull) return qe;
     const int lane = (int)(threadIdx.x & 63u);
     const unsigned int key = in ? (((unsigned int)gy << 15) | (unsigned int)gx) : 0xffffffffu;   // gx, gy < 32768
     const unsigned int prev = (unsigned int)__shfl_up((int)key, 1);
@@ -350,10 +371,22 @@ __device__ __forceinline__ void vote(const MvFields m, const ScanK &k, int t0, i
         unsigned int base = 0u;
         if (lane == leader) base = atomicAdd(sq.tail, (unsigned int)__popcll(qm));
         base = (unsigned int)__shfl((int)base, leader);
-        if (qv) sq.q[base + (unsigned int)__popcll(qm & ((1ull << lane) - 1ull))] = ((min(run, 4u) - 1u) << 30) | key;
+        if (qv) {
+          qe.off = (base + (unsigned int)__popcll(qm & ((1ull << lane) - 1ull))) << 2;
+          qe.e = ((min(run, 4u) - 1u) << 30) | key;
+        }
       }
     }
+    return qe;
   }
+}
+
+// vote + the queue store right behind it (head records, tails, pre-issued steps: outside the streaming loop)
+template <int FB, int MODE, bool SPILL, bool DROP>
+__device__ __forceinline__ void vote_now(const MvFields m, const ScanK &k, int t0, int t1, unsigned int *cnt,
+                                         const SpillQ &sq) {
+  const QEntry qe = vote<FB, MODE, SPILL>(m, k, t0, t1, cnt, sq);
+  if constexpr (SPILL) queue_store<DROP>(sq, qe);
 }
 
 // Compact records: how many records at the start of a frame's array are scanned one by one so that the
@@ -385,6 +418,14 @@ __device__ __forceinline__ void scan_item(
     unsigned int *spill_q, unsigned int *slice_ws, unsigned int *tickets, unsigned int *lds,
     NextStep<UNROLL> &ns, const bool has_next) {
   typedef typename RawOf<REC>::type Raw;
+  // Banded plans (SPILL), how the queue is written — VAR bits, chosen per build by launch_form:
+  //   16 DEFER  the queue stores of a streaming step are issued after the step's last vote, not between its loads
+  //    8 PIPE   the next step's loads are issued before this step's votes (software pipelining)
+  //   32 DROP   branch-free stores: lanes without an entry store beyond the buffer (queue_store)
+  //   64 DEEP   the replay keeps 8 queue loads in flight per lane instead of 4
+  constexpr bool DROP = SPILL && (VAR & 32) != 0;
+  constexpr bool DEFER = SPILL && (VAR & 16) != 0;
+  constexpr bool DEEP = SPILL && (VAR & 64) != 0;
   const int tid = threadIdx.x;
   // item -> frame, or (frame, slice): bands and slices are never both > 1
   PT_DECL;
@@ -419,6 +460,8 @@ __device__ __forceinline__ void scan_item(
   unsigned int *ticket = total + 1;
   SpillQ sq;
   sq.q = SPILL ? spill_q + q0 : nullptr;
+  sq.rsrc = __builtin_amdgcn_make_buffer_rsrc(SPILL ? (void *)(spill_q + q0) : (void *)lds, 0,
+                                              (DROP && (r1 - r0) < (1ull << 30)) ? (int)((r1 - r0) * 4ull) : 0, 0x00020000);
   sq.tail = total + 2;
   sq.q_lo = min(k.y_hi, k.y_lo + k.band_rows) - 1;                 // band 0's last centre row
 
@@ -459,7 +502,7 @@ __device__ __forceinline__ void scan_item(
             unsigned long long h = (unsigned long long)((13u * ((16u - (r >> 3)) & 15u)) & 15u);
             h = h < n ? h : n;
             if ((unsigned long long)tid < h)
-              vote<FB, MODE, SPILL>(decode(load_rec<VAR, REC>(base + (unsigned long long)tid * REC)), k, t0, t1, cnt, sq);
+              vote_now<FB, MODE, SPILL, DROP>(decode(load_rec<VAR, REC>(base + (unsigned long long)tid * REC)), k, t0, t1, cnt, sq);
             base += h * (unsigned long long)REC;
             n -= h;
           }
@@ -477,18 +520,45 @@ __device__ __forceinline__ void scan_item(
           const unsigned char *pbase = base + head * 8ull;
           const unsigned long long np = (n - head) >> 1;            // pairs
           if ((unsigned long long)tid < head)
-            vote<FB, MODE, SPILL>(decode(load_compact<VAR>(base + (unsigned long long)tid * 8ull)), k, t0, t1, cnt, sq);
+            vote_now<FB, MODE, SPILL, DROP>(decode(load_compact<VAR>(base + (unsigned long long)tid * 8ull)), k, t0, t1, cnt, sq);
           if (tid == 0 && ((n - head) & 1ull) != 0ull)
-            vote<FB, MODE, SPILL>(decode(load_compact<VAR>(base + (n - 1ull) * 8ull)), k, t0, t1, cnt, sq);
+            vote_now<FB, MODE, SPILL, DROP>(decode(load_compact<VAR>(base + (n - 1ull) * 8ull)), k, t0, t1, cnt, sq);
           unsigned long long p = tid;
           if (ns.have) {                       // this frame's first step (ns.frame == f, checked on entry) was issued during
             ns.have = false;                   // the previous frame's cluster test
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) {
-              vote<FB, MODE, SPILL>(decode((u32x2){ns.d[u].x, ns.d[u].y}), k, t0, t1, cnt, sq);
-              vote<FB, MODE, SPILL>(decode((u32x2){ns.d[u].z, ns.d[u].w}), k, t0, t1, cnt, sq);
+              vote_now<FB, MODE, SPILL, DROP>(decode((u32x2){ns.d[u].x, ns.d[u].y}), k, t0, t1, cnt, sq);
+              vote_now<FB, MODE, SPILL, DROP>(decode((u32x2){ns.d[u].z, ns.d[u].w}), k, t0, t1, cnt, sq);
             }
             p += STEP;
+          }
+          if constexpr (SPILL && (VAR & 8) != 0) {
+            // banded plans: software-pipelined, see the 40-byte loop below ("PIPE")
+            if (p + LAST < np) {
+              u32x4 cur[UNROLL], nxt[UNROLL];
+#pragma unroll
+              for (int u = 0; u < UNROLL; ++u) cur[u] = load_pair<VAR>(pbase + (p + (unsigned long long)u * BLOCK) * 16ull);
+              for (;;) {
+                const unsigned long long j = p + STEP;
+                const bool more = j + LAST < np;
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u)
+                  nxt[u] = load_pair<VAR>(more ? pbase + (j + (unsigned long long)u * BLOCK) * 16ull : pbase);
+                QEntry qe[2 * UNROLL];
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) {
+                  qe[2 * u] = vote<FB, MODE, SPILL>(decode((u32x2){cur[u].x, cur[u].y}), k, t0, t1, cnt, sq);
+                  qe[2 * u + 1] = vote<FB, MODE, SPILL>(decode((u32x2){cur[u].z, cur[u].w}), k, t0, t1, cnt, sq);
+                }
+#pragma unroll
+                for (int u = 0; u < 2 * UNROLL; ++u) queue_store<DROP>(sq, qe[u]);
+                p = j;
+                if (!more) break;
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) cur[u] = nxt[u];
+              }
+            }
           }
           for (; p + LAST < np; p += STEP) {
             u32x4 d[UNROLL];
@@ -497,8 +567,8 @@ __device__ __forceinline__ void scan_item(
             __builtin_amdgcn_sched_barrier(0);   // every load of the step is issued before the first one is consumed
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) {
-              vote<FB, MODE, SPILL>(decode((u32x2){d[u].x, d[u].y}), k, t0, t1, cnt, sq);
-              vote<FB, MODE, SPILL>(decode((u32x2){d[u].z, d[u].w}), k, t0, t1, cnt, sq);
+              vote_now<FB, MODE, SPILL, DROP>(decode((u32x2){d[u].x, d[u].y}), k, t0, t1, cnt, sq);
+              vote_now<FB, MODE, SPILL, DROP>(decode((u32x2){d[u].z, d[u].w}), k, t0, t1, cnt, sq);
             }
           }
           {
@@ -515,34 +585,46 @@ __device__ __forceinline__ void scan_item(
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u)
               if (ok[u]) {
-                vote<FB, MODE, SPILL>(decode((u32x2){d[u].x, d[u].y}), k, t0, t1, cnt, sq);
-                vote<FB, MODE, SPILL>(decode((u32x2){d[u].z, d[u].w}), k, t0, t1, cnt, sq);
+                vote_now<FB, MODE, SPILL, DROP>(decode((u32x2){d[u].x, d[u].y}), k, t0, t1, cnt, sq);
+                vote_now<FB, MODE, SPILL, DROP>(decode((u32x2){d[u].z, d[u].w}), k, t0, t1, cnt, sq);
               }
           }
           i = n;                                                    // nothing left for the generic tail loop
         } else if constexpr ((VAR & 8) != 0) {
-          // software-pipelined: the next batch of loads is issued before this batch is consumed
-          Raw cur[UNROLL], nxt[UNROLL];
-          bool have = i + LAST < n;
-          if (have) {
+          // PIPE — software-pipelined: the next step's loads are issued before this step is consumed, so a wave that
+          // votes (returning LDS atomics: dependent round trips) keeps its loads in flight meanwhile.  Two details
+          // decide whether that works at all, both about how the compiler counts pending vector-memory operations
+          // (s_waitcnt vmcnt is a static number, the minimum over every path that reaches it):
+          //  - the prefetch is UNCONDITIONAL: after the last full step it reads one dummy address (the frame's first
+          //    bytes, one line per wave instruction) instead of being skipped — under `if (more)` the compiler must
+          //    assume the loads were not issued and waits for them before it lets the current step be used (round 4
+          //    measured exactly that form as "no gain");
+          //  - queue stores are issued after the step's last vote (DEFER) and, with DROP, without a branch.
+          if (i + LAST < n) {
+            Raw cur[UNROLL], nxt[UNROLL];
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) cur[u] = load_rec<VAR, REC>(base + (i + (unsigned long long)u * BLOCK) * REC);
-          }
-          while (have) {
-            const unsigned long long j = i + STEP;
-            const bool more = j + LAST < n;
-            if (more) {
+            for (;;) {
+              const unsigned long long j = i + STEP;
+              const bool more = j + LAST < n;
 #pragma unroll
-              for (int u = 0; u < UNROLL; ++u) nxt[u] = load_rec<VAR, REC>(base + (j + (unsigned long long)u * BLOCK) * REC);
-            }
+              for (int u = 0; u < UNROLL; ++u)
+                nxt[u] = load_rec<VAR, REC>(more ? base + (j + (unsigned long long)u * BLOCK) * REC : base);
+              if constexpr (DEFER) {
+                QEntry qe[UNROLL];
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) vote<FB, MODE, SPILL>(decode(cur[u]), k, t0, t1, cnt, sq);
-            if (more) {
+                for (int u = 0; u < UNROLL; ++u) qe[u] = vote<FB, MODE, SPILL>(decode(cur[u]), k, t0, t1, cnt, sq);
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) queue_store<DROP>(sq, qe[u]);
+              } else {
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) vote_now<FB, MODE, SPILL, DROP>(decode(cur[u]), k, t0, t1, cnt, sq);
+              }
+              i = j;
+              if (!more) break;
 #pragma unroll
               for (int u = 0; u < UNROLL; ++u) cur[u] = nxt[u];
             }
-            i = j;
-            have = more;
           }
         } else {
           // main body: UNROLL independent loads in flight per lane
@@ -552,8 +634,16 @@ __device__ __forceinline__ void scan_item(
             for (int u = 0; u < UNROLL; ++u) d[u] = load_rec<VAR, REC>(base + (i + (unsigned long long)u * BLOCK) * REC);
             // (the scheduler sinks loads 2..UNROLL below the wait for load 1; forcing them up front with
             //  a sched_barrier measured -1..-2 % here, +7 % in the compact loop above: left as it is)
+            if constexpr (DEFER) {
+              QEntry qe[UNROLL];
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) vote<FB, MODE, SPILL>(decode(d[u]), k, t0, t1, cnt, sq);
+              for (int u = 0; u < UNROLL; ++u) qe[u] = vote<FB, MODE, SPILL>(decode(d[u]), k, t0, t1, cnt, sq);
+#pragma unroll
+              for (int u = 0; u < UNROLL; ++u) queue_store<DROP>(sq, qe[u]);
+            } else {
+#pragma unroll
+              for (int u = 0; u < UNROLL; ++u) vote_now<FB, MODE, SPILL, DROP>(decode(d[u]), k, t0, t1, cnt, sq);
+            }
           }
         }
         if (i < n) {
@@ -570,7 +660,7 @@ __device__ __forceinline__ void scan_item(
           }
 #pragma unroll
           for (int u = 0; u < TU; ++u)
-            if (ok[u]) vote<FB, MODE, SPILL>(decode(d[u]), k, t0, t1, cnt, sq);
+            if (ok[u]) vote_now<FB, MODE, SPILL, DROP>(decode(d[u]), k, t0, t1, cnt, sq);
         }
       }
       if constexpr (REC == 8 && !SPILL) {
@@ -599,6 +689,18 @@ __device__ __forceinline__ void scan_item(
     } else {                                   // replay the votes band 0 queued for later bands
       const unsigned int nq = *sq.tail;
       unsigned int i = (unsigned int)tid;
+      if constexpr (DEEP) {
+        for (; i + 7u * BLOCK < nq; i += 8u * BLOCK) {
+          unsigned int e[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) e[u] = sq.q[i + (unsigned int)u * BLOCK];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int gy = (int)((e[u] >> 15) & 0x7fffu), gx = (int)(e[u] & 0x7fffu);
+            if (gy >= t0 && gy < t1) bump_n<FB, MODE>(cnt, (unsigned int)((gy - t0) * k.gw + gx), (e[u] >> 30) + 1u, k.vec_need);
+          }
+        }
+      }
       for (; i + 3u * BLOCK < nq; i += 4u * BLOCK) {
         unsigned int e[4];
 #pragma unroll
@@ -896,16 +998,52 @@ static hipError_t launch_variant(const ScanLaunch &L) {
 }
 #endif
 
+// How banded plans write and replay their queue (scan_item: DEFER / PIPE / DROP / DEEP).  One choice per build;
+// the experiments build can select any combination for the 4-bit thermometer form on 40-byte records
+// (MTGPU_VARIANT bits 8 | 16 | 32 | 64) to compare them in one process.
+constexpr int SPILL_VAR = 0;
+
+#ifdef MTGPU_EXPERIMENTS
+template <int BLOCK>
+static hipError_t launch_spill_variant(const ScanLaunch &L) {
+  switch (L.variant & (8 | 16 | 32 | 64)) {
+#define MT_SPILL_CASE(v) case v: return launch_one<BLOCK, 4, MODE_UNARY, 40, true, 4, (v)>(L);
+    MT_SPILL_CASE(0) MT_SPILL_CASE(8) MT_SPILL_CASE(16) MT_SPILL_CASE(24) MT_SPILL_CASE(32) MT_SPILL_CASE(40)
+    MT_SPILL_CASE(48) MT_SPILL_CASE(56) MT_SPILL_CASE(64) MT_SPILL_CASE(72) MT_SPILL_CASE(80) MT_SPILL_CASE(88)
+    MT_SPILL_CASE(96) MT_SPILL_CASE(104) MT_SPILL_CASE(112) MT_SPILL_CASE(120)
+#undef MT_SPILL_CASE
+    default: return hipErrorInvalidValue;
+  }
+}
+#endif
+
+// One counter form of a plan.  Banded plans (SPILL) run the SPILL_VAR flavour of the queue code; its branch-free
+// DROP stores address the frame's queue with 32-bit byte offsets, so batches of 2^30 records and more (every frame
+// is then not known to fit) take the same kernel without DROP.
+template <int BLOCK, int FB, int MODE, int REC, bool SPILL>
+static hipError_t launch_counter_form(const ScanLaunch &L) {
+  if constexpr (SPILL) {
+    if (L.n_records < (1ull << 30)) return launch_one<BLOCK, FB, MODE, REC, true, 4, SPILL_VAR>(L);
+    return launch_one<BLOCK, FB, MODE, REC, true, 4, (SPILL_VAR & ~32)>(L);
+  } else {
+    return launch_one<BLOCK, FB, MODE, REC, false>(L);
+  }
+}
+
 template <int BLOCK, int REC, bool SPILL>
 static hipError_t launch_form(const ScanLaunch &L) {
   const int key = L.k.mode * 100 + L.k.fb;
+#ifdef MTGPU_EXPERIMENTS
+  if constexpr (SPILL && REC == 40 && BLOCK == 1024)
+    if (key == MODE_UNARY * 100 + 4 && (L.variant & 128) != 0) return launch_spill_variant<BLOCK>(L);
+#endif
   switch (key) {
-    case MODE_ADD32 * 100 + 32: return launch_one<BLOCK, 32, MODE_ADD32, REC, SPILL>(L);
-    case MODE_UNARY * 100 + 1: return launch_one<BLOCK, 1, MODE_UNARY, REC, SPILL>(L);
-    case MODE_UNARY * 100 + 2: return launch_one<BLOCK, 2, MODE_UNARY, REC, SPILL>(L);
-    case MODE_UNARY * 100 + 4: return launch_one<BLOCK, 4, MODE_UNARY, REC, SPILL>(L);
-    case MODE_UNARY * 100 + 8: return launch_one<BLOCK, 8, MODE_UNARY, REC, SPILL>(L);
-    case MODE_CAS * 100 + 8: return launch_one<BLOCK, 8, MODE_CAS, REC, SPILL>(L);
+    case MODE_ADD32 * 100 + 32: return launch_counter_form<BLOCK, 32, MODE_ADD32, REC, SPILL>(L);
+    case MODE_UNARY * 100 + 1: return launch_counter_form<BLOCK, 1, MODE_UNARY, REC, SPILL>(L);
+    case MODE_UNARY * 100 + 2: return launch_counter_form<BLOCK, 2, MODE_UNARY, REC, SPILL>(L);
+    case MODE_UNARY * 100 + 4: return launch_counter_form<BLOCK, 4, MODE_UNARY, REC, SPILL>(L);
+    case MODE_UNARY * 100 + 8: return launch_counter_form<BLOCK, 8, MODE_UNARY, REC, SPILL>(L);
+    case MODE_CAS * 100 + 8: return launch_counter_form<BLOCK, 8, MODE_CAS, REC, SPILL>(L);
     default: return hipErrorInvalidValue;
   }
 }
