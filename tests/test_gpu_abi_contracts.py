@@ -46,4 +46,4 @@ def test_every_caller_sized_buffer_is_respected(tmp_path):
     assert "all caller-sized buffers respected" in out.stdout
     # the canaries do catch an under-stated size: with d_ts sized as round 4's header had it, the program fails on d_ts
     bad = subprocess.run([exe, "round4-header"], capture_output=True, text=True)
-    assert bad.returncode == 1 and "d_ts (n_frames doubles) was overrun" in bad.stderr, bad.stdout + bad.stderr
+    assert bad.returncode == 1 and "d_ts (n_frames doubles)" in bad.stderr and "was overrun" in bad.stderr, bad.stdout + bad.stderr
