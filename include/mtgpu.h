@@ -148,8 +148,13 @@ int mtgpu_plan_preview(const mt_scan_params *params, int lds_bytes_per_workgroup
  * Results never depend on it. */
 int mtgpu_set_slices(mtgpu_ctx *ctx, int slices);
 
-/* Calibration only (bench.py): stream `bytes` of a device buffer with the scan's load flavour
- * and discard them — the chip's pure-read ceiling on that buffer.  Asynchronous on `stream`. */
+/* Calibration only (bench.py): stream `bytes` of a device buffer and discard them — what a kernel that ONLY reads
+ * reaches on that buffer.  shape 0: 16 contiguous bytes per lane; shape 1: the scan's own access (bytes 4..15 of
+ * every 40-byte record); chunk_bytes: contiguous bytes per 512-thread workgroup (0 = 1.25 MiB; one frame's bytes
+ * makes shape 1 the scan kernel minus its votes).  bench.py reports the best of a small sweep as the measured
+ * ceiling.  Asynchronous on `stream`.  mtgpu_debug_read_ceiling = shape 0, default chunk. */
+int mtgpu_debug_read_ceiling_shape(mtgpu_ctx *ctx, const void *d_buf, uint64_t bytes, int shape, uint64_t chunk_bytes,
+                                   void *stream);
 int mtgpu_debug_read_ceiling(mtgpu_ctx *ctx, const void *d_buf, uint64_t bytes, void *stream);
 
 /*

@@ -55,7 +55,8 @@ hipError_t launch_scan(const ScanLaunch &L);
 // *first_bad (device, pre-set to 0xffffffff) = smallest f with frame_off[f] > frame_off[f + 1]
 hipError_t launch_check_offsets(const unsigned long long *frame_off, unsigned int n_frames, unsigned int *first_bad,
                                 hipStream_t stream);
-hipError_t launch_read_ceiling(const void *p, unsigned long long bytes, unsigned int *sink, int cu_count,
-                               hipStream_t stream);
+// calibration: shape 0 = 16 contiguous bytes per lane, 1 = the scan's 12-of-40-byte records; chunk = bytes per workgroup (0: 1.25 MiB)
+hipError_t launch_read_ceiling(const void *p, unsigned long long bytes, int shape, unsigned long long chunk,
+                               unsigned int *sink, hipStream_t stream);
 
 }  // namespace mtgpu

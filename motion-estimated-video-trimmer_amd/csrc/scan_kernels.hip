@@ -896,38 +896,65 @@ __global__ __launch_bounds__(BLOCK) void scan_frames_kernel(
   }
 }
 
-// Calibration only: a pure streaming read shaped like the scan (one workgroup per contiguous
-// 1.25 MiB chunk, 512 threads, nt loads, 4 x 16 B in flight per lane, nothing else), folded into
-// a value that is (almost) never stored.  bench.py reports its rate on the scan's own record
-// buffer beside the 8 TB/s spec peak: what a kernel that ONLY reads can reach on this chip.
-constexpr unsigned long long READ_CHUNK16 = (1280ull * 1024ull) / 16ull;
-
-__global__ __launch_bounds__(512) void read_ceiling_kernel(const u32x4 *__restrict__ p, unsigned long long n16,
-                                                           unsigned int *__restrict__ sink) {
-  const unsigned long long b0 = (unsigned long long)blockIdx.x * READ_CHUNK16;
-  const unsigned long long b1 = min(n16, b0 + READ_CHUNK16);
-  unsigned long long i = b0 + threadIdx.x;
-  u32x4 acc = (u32x4){0u, 0u, 0u, 0u};
-  for (; i + 3ull * 512ull < b1; i += 4ull * 512ull) {
-    u32x4 v[4];
+// Calibration only: a kernel that ONLY reads, so that bench.py can state what a pure read reaches on the very buffer
+// the scan streams ("measured read ceiling", beside the 8 TB/s spec peak).  One workgroup of 512 threads per
+// contiguous chunk, nt loads, four in flight per lane, folded into a value that is (almost) never stored.  Two load
+// shapes — a ceiling has to be at least as good as what it bounds, so bench.py sweeps both (and a few chunk sizes)
+// and reports the best:
+//   SHAPE 0  16 contiguous bytes per lane (every byte of the buffer crosses into the CU)
+//   SHAPE 1  the scan's own: bytes 4..15 of every 40-byte record, one record per lane (every LINE is fetched, 12 of
+//            40 bytes reach the registers) — with a chunk of one frame this is the scan kernel minus its votes
+template <int SHAPE>
+__global__ __launch_bounds__(512) void read_ceiling_kernel(const unsigned char *__restrict__ p, unsigned long long bytes,
+                                                           unsigned long long chunk, unsigned int *__restrict__ sink) {
+  const unsigned long long c0 = (unsigned long long)blockIdx.x * chunk;
+  const unsigned long long c1 = min(bytes, c0 + chunk);
+  constexpr unsigned long long UNIT = SHAPE == 0 ? 16ull : 40ull;
+  const unsigned char *base = p + c0;
+  const unsigned long long n = (c1 - c0) / UNIT;
+  unsigned long long i = threadIdx.x;
+  unsigned int acc = 0u;
+  for (; i + 3ull * 512ull < n; i += 4ull * 512ull) {
+    if constexpr (SHAPE == 0) {
+      u32x4 v[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) v[u] = __builtin_nontemporal_load(p + i + (unsigned long long)u * 512ull);
+      for (int u = 0; u < 4; ++u) v[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_a16 *>(base + (i + (unsigned long long)u * 512ull) * 16ull));
 #pragma unroll
-    for (int u = 0; u < 4; ++u) acc ^= v[u];
+      for (int u = 0; u < 4; ++u) acc ^= v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+    } else {
+      u32x3 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = load_fields<0>(base + (i + (unsigned long long)u * 512ull) * 40ull);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc ^= v[u].x ^ v[u].y ^ v[u].z;
+    }
   }
-  for (; i < b1; i += 512ull) acc ^= __builtin_nontemporal_load(p + i);
-  if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9E3779B9u) *sink = acc.x;   // keeps the loads alive
+  for (; i < n; i += 512ull) {
+    if constexpr (SHAPE == 0) {
+      const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_a16 *>(base + i * 16ull));
+      acc ^= v.x ^ v.y ^ v.z ^ v.w;
+    } else {
+      const u32x3 v = load_fields<0>(base + i * 40ull);
+      acc ^= v.x ^ v.y ^ v.z;
+    }
+  }
+  if (acc == 0x9E3779B9u) *sink = acc;   // keeps the loads alive
 }
 
-hipError_t launch_read_ceiling(const void *p, unsigned long long bytes, unsigned int *sink, int cu_count,
-                               hipStream_t stream) {
-  (void)cu_count;
-  const unsigned long long n16 = bytes / 16ull;
-  if (n16 == 0) return hipSuccess;
-  const unsigned long long blocks = (n16 + READ_CHUNK16 - 1) / READ_CHUNK16;
+hipError_t launch_read_ceiling(const void *p, unsigned long long bytes, int shape, unsigned long long chunk,
+                               unsigned int *sink, hipStream_t stream) {
+  if (chunk == 0) chunk = 1280ull * 1024ull;
+  if (shape == 0) chunk &= ~15ull;           // chunks of whole 16-byte units (the buffer itself is 16-byte aligned)
+  else chunk -= chunk % 40ull;               // ... of whole records
+  if (chunk == 0 || bytes < chunk) return hipSuccess;
+  const unsigned long long blocks = (bytes + chunk - 1) / chunk;
   if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(read_ceiling_kernel, dim3((unsigned int)blocks), dim3(512), 0, stream,
-                     static_cast<const u32x4 *>(p), n16, sink);
+  if (shape == 0)
+    hipLaunchKernelGGL(read_ceiling_kernel<0>, dim3((unsigned int)blocks), dim3(512), 0, stream,
+                       static_cast<const unsigned char *>(p), bytes, chunk, sink);
+  else
+    hipLaunchKernelGGL(read_ceiling_kernel<1>, dim3((unsigned int)blocks), dim3(512), 0, stream,
+                       static_cast<const unsigned char *>(p), bytes, chunk, sink);
   return hipGetLastError();
 }
 

@@ -209,3 +209,31 @@ def test_launcher_watchdog_ends_a_hung_run_and_keeps_the_evidence(tmp_path, monk
     assert bench.launch_ranks(a, ["--gpus", "2"], environ=dict(os.environ), popen=probe_popen, report=reports.append) == 124
     assert _t.monotonic() - t0 < 20
     assert os.path.exists(str(tmp_path / "bench_rank1.err.stderr.log"))
+
+
+def test_rank_under_torchrun_sets_the_ipc_mode_before_the_gpu_runtime_starts():
+    """Under `python -m torch.distributed.run ... bench.py --gpus N` (the driver's N > 1 command) no launcher of ours
+    builds the rank's environment: the rank itself must set HSA_ENABLE_IPC_MODE_LEGACY=0 (RCCL on this pool) before
+    torch — hence HIP — is imported; a value the caller exported is left alone; a single rank sets nothing."""
+    import inspect
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.prepare_rank_environment({}, True) == {"HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+    assert bench.prepare_rank_environment({"HSA_ENABLE_IPC_MODE_LEGACY": "1"}, True) == {"HSA_ENABLE_IPC_MODE_LEGACY": "1"}
+    assert bench.prepare_rank_environment({}, False) == {}
+    src = inspect.getsource(bench._run_rank)
+    assert 0 < src.index("prepare_rank_environment(os.environ, multi)") < src.index("import torch")
+
+
+def test_bench_line_config_is_machine_readable_when_truncated():
+    """The driver's record keeps only the head of long strings: `config.workload` must show the parameter set within
+    its first 100 characters, and the details live in keys of their own."""
+    import inspect
+    sys.path.insert(0, ROOT)
+    import bench
+    src = inspect.getsource(bench._run_rank)
+    a = bench.parse([])
+    wl = f"{a.workload} params={a.params} grid=120x68 frames/GPU/step={a.frames}"
+    assert len(wl) < 100 and "params=code_defaults" in wl
+    assert 'f"{a.workload} params={a.params} grid=' in src and '"distinct_frames_tiled": a.distinct' in src
+    assert '"vs_cpu_baseline_same_quota"' in src
