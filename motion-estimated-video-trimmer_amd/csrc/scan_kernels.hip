@@ -309,9 +309,9 @@ constexpr unsigned int NO_SLOT = 0xffffffffu;
 // issued before it may use the next load of the same step — a store round trip per step, serialised with the loads.
 // DROP: every lane stores, lanes without an entry at an offset beyond the buffer, where the hardware discards the
 // store: no branch, exact counts, and a wave never waits for a queue store (only before the replay, vmcnt(0)).
-template <bool DROP>
+template <bool DROP, int AUX = 0>
 __device__ __forceinline__ void queue_store(const SpillQ &sq, const QEntry qe) {
-  if constexpr (DROP) __builtin_amdgcn_raw_buffer_store_b32(qe.e, sq.rsrc, qe.off, 0, 0);
+  if constexpr (DROP) __builtin_amdgcn_raw_buffer_store_b32(qe.e, sq.rsrc, qe.off, 0, AUX);   // AUX: 1 sc0, 2 nt, 16 sc1
   else if (qe.off != NO_SLOT) sq.q[qe.off >> 2] = qe.e;
 }
 
@@ -381,6 +381,161 @@ __device__ __forceinline__ QEntry vote(const MvFields m, const ScanK &k, int t0,
   }
 }
 
+// Lane l reads lane l-1's value (lane 0: `fill`): one DPP move inside the VALU (wave_shr:1, gfx9 family), where
+// __shfl_up goes through the LDS crossbar (ds_bpermute_b32: an LDS-pipe instruction and a wait).  Full EXEC only.
+__device__ __forceinline__ unsigned int from_lane_below(unsigned int v, unsigned int fill) {
+  return (unsigned int)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+
+// The votes of one streaming STEP — U records per lane, every lane of the wave active — for thermometer fields
+// (MODE_UNARY, FB >= 2), with the same final counter state and the same queue entries (in the same order) as U calls
+// of vote().  vote() handles a record from its load to its queue slot before the next one starts: per record a
+// crossbar shuffle, a look at the field, a returning OR, a returning add on the queue tail, a second shuffle — five
+// LDS-pipe round trips, each waited for, 146 instructions; on input where every record votes that chain, not memory,
+// is what a wave spends its life in (round 4: 0.65-0.75 of the roofline on banded plans).  Here the U records move
+// through each stage together: U looks in flight, then U ORs in flight, ONE add on the queue tail for the whole step,
+// DPP / readfirstlane in place of the shuffles.  Votes that lose a race (another wave set the bit between look and
+// OR) settle in the same retry loop as bump_n.  A step in which no lane votes costs U ballots.
+template <int FB, int MODE, bool SPILL, int U, int ABL = 0>
+__device__ __forceinline__ void vote_step(const MvFields (&m)[U], const ScanK &k, int t0, int t1, unsigned int *cnt,
+                                          const SpillQ &sq, QEntry (&qe)[U]) {
+  static_assert(MODE == MODE_UNARY && FB >= 2 && FB <= 8, "thermometer fields only");
+  constexpr unsigned int FM = (1u << FB) - 1u;
+  const unsigned int lane = threadIdx.x & 63u;
+  bool in[U];
+  unsigned int key[U];
+  int gy[U];
+  unsigned long long any = 0ull;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const unsigned int dx = (unsigned int)(m[u].dst_x - m[u].src_x), dy = (unsigned int)(m[u].dst_y - m[u].src_y);
+    const unsigned long long mag = (unsigned long long)(dx * dx) + (unsigned long long)(dy * dy);   // see vote()
+    const int gx = m[u].dst_x >> k.shift;
+    gy[u] = m[u].dst_y >> k.shift;
+    in[u] = (mag >= k.thr) & ((unsigned int)gx < (unsigned int)k.gw) &
+            ((unsigned int)(gy[u] - k.y_lo) < (unsigned int)(k.y_hi - k.y_lo));
+    key[u] = in[u] ? (((unsigned int)gy[u] << 15) | (unsigned int)gx) : 0xffffffffu;
+    any |= __ballot(in[u]);
+    qe[u].off = NO_SLOT;
+    qe[u].e = 0u;
+  }
+  if (any == 0ull) return;
+  // runs of equal cells inside each wave instruction (see vote(): same cut rules, every lane is active here)
+  const unsigned long long forced = (k.vec_need > 4u) ? 0x1111111111111111ull : 1ull;
+  bool head[U];
+  unsigned int run[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const unsigned int prev = from_lane_below(key[u], ~key[u]);
+    const unsigned long long heads = __ballot(key[u] != prev) | forced;
+    head[u] = ((heads >> lane) & 1ull) != 0ull;
+    const unsigned long long above = (lane < 63u) ? (heads >> (lane + 1u)) : 0ull;
+    run[u] = above ? (unsigned int)__ffsll((long long)above) : (64u - lane);
+  }
+  // stage 1: the looks, all in flight
+  bool mine[U];
+  unsigned int *w[U];
+  unsigned int sh[U], f[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    mine[u] = in[u] & head[u];
+    if constexpr (SPILL) mine[u] = mine[u] & ((unsigned int)(gy[u] - t0) < (unsigned int)(t1 - t0));
+    const unsigned int cell = mine[u] ? (unsigned int)((gy[u] - t0) * k.gw + (int)(key[u] & 0x7fffu)) : 0u;
+    const unsigned int bit = cell * (unsigned int)FB;
+    w[u] = &cnt[bit >> 5];
+    sh[u] = bit & 31u;
+    f[u] = 0u;
+  }
+  if constexpr ((ABL & 1024) != 0) {                      // ablation (experiments build): no LDS votes
+#pragma unroll
+    for (int u = 0; u < U; ++u) mine[u] = false;
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+    if (mine[u]) f[u] = *w[u];
+  // stage 2: one returning OR each, all in flight
+  unsigned int left[U], j[U], mk[U], fo[U];
+  bool act[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    j[u] = (unsigned int)__popc((f[u] >> sh[u]) & FM);
+    left[u] = min(run[u], k.vec_need);
+    act[u] = mine[u] & (j[u] < k.vec_need) & (left[u] != 0u);
+    const unsigned int take = min(left[u], k.vec_need - min(j[u], k.vec_need));
+    mk[u] = ((1u << take) - 1u) << j[u];
+    fo[u] = 0u;
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+    if (act[u]) fo[u] = (atomicOr(w[u], mk[u] << sh[u]) >> sh[u]) & FM;
+  // stage 3: bits somebody else set between look and OR do not count for this lane: it continues above them
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+    if (act[u]) {
+      unsigned int l = left[u] - (unsigned int)__popc(mk[u] & ~fo[u]);
+      unsigned int jj = (unsigned int)__popc(fo[u] | mk[u]);
+      while (l != 0u && jj < k.vec_need) {
+        const unsigned int take = min(l, k.vec_need - jj);
+        const unsigned int m2 = ((1u << take) - 1u) << jj;
+        const unsigned int o2 = (atomicOr(w[u], m2 << sh[u]) >> sh[u]) & FM;
+        l -= (unsigned int)__popc(m2 & ~o2);
+        jj = (unsigned int)__popc(o2 | m2);
+      }
+    }
+  if constexpr (SPILL) {
+    // the step's queue entries: one returning add on the tail for all of them, slots in record order
+    unsigned long long qm[U];
+    bool qv[U];
+    unsigned int total = 0u, before[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      qv[u] = in[u] & head[u] & (gy[u] >= sq.q_lo);
+      qm[u] = __ballot(qv[u]);
+      before[u] = total;
+      total += (unsigned int)__popcll(qm[u]);
+    }
+    if (total != 0u) {
+      unsigned int base = 0u;
+      if (lane == 0u) base = atomicAdd(sq.tail, total);
+      base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (qv[u]) {
+          const unsigned int below = __builtin_amdgcn_mbcnt_hi((unsigned int)(qm[u] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)qm[u], 0u));
+          qe[u].off = (ABL & 512) != 0 ? NO_SLOT : (base + before[u] + below) << 2;    // ablation: nothing is stored
+          qe[u].e = ((min(run[u], 4u) - 1u) << 30) | key[u];
+        }
+    }
+  }
+}
+
+// One streaming step of U decoded records per lane (every lane active): batched (vote_step) where the counter form has
+// it and the build asks for it (STEP), else record by record; queue stores after the last vote (DEFER) or right away.
+template <int FB, int MODE, bool SPILL, bool STEP, bool DEFER, bool DROP, int U, int ABL = 0>
+__device__ __forceinline__ void vote_records(const MvFields (&m)[U], const ScanK &k, int t0, int t1, unsigned int *cnt,
+                                             const SpillQ &sq) {
+  if constexpr (STEP && MODE == MODE_UNARY && FB >= 2) {
+    QEntry qe[U];
+    vote_step<FB, MODE, SPILL, U, ABL>(m, k, t0, t1, cnt, sq, qe);
+    if constexpr (SPILL) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) queue_store<DROP, ((ABL & 4096) ? 2 : 0) | ((ABL & 8192) ? 16 : 0)>(sq, qe[u]);
+    }
+  } else if constexpr (SPILL && DEFER) {
+    QEntry qe[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) qe[u] = vote<FB, MODE, SPILL>(m[u], k, t0, t1, cnt, sq);
+#pragma unroll
+    for (int u = 0; u < U; ++u) queue_store<DROP>(sq, qe[u]);
+  } else {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const QEntry qe = vote<FB, MODE, SPILL>(m[u], k, t0, t1, cnt, sq);
+      if constexpr (SPILL) queue_store<DROP>(sq, qe);
+    }
+  }
+}
+
 // vote + the queue store right behind it (head records, tails, pre-issued steps: outside the streaming loop)
 template <int FB, int MODE, bool SPILL, bool DROP>
 __device__ __forceinline__ void vote_now(const MvFields m, const ScanK &k, int t0, int t1, unsigned int *cnt,
@@ -426,6 +581,8 @@ __device__ __forceinline__ void scan_item(
   constexpr bool DROP = SPILL && (VAR & 32) != 0;
   constexpr bool DEFER = SPILL && (VAR & 16) != 0;
   constexpr bool DEEP = SPILL && (VAR & 64) != 0;
+  //  256 BATCH  the records of a streaming step vote together (vote_step: thermometer fields; any plan, banded or not)
+  constexpr bool BATCH = (VAR & 256) != 0;
   const int tid = threadIdx.x;
   // item -> frame, or (frame, slice): bands and slices are never both > 1
   PT_DECL;
@@ -545,14 +702,16 @@ __device__ __forceinline__ void scan_item(
 #pragma unroll
                 for (int u = 0; u < UNROLL; ++u)
                   nxt[u] = load_pair<VAR>(more ? pbase + (j + (unsigned long long)u * BLOCK) * 16ull : pbase);
-                QEntry qe[2 * UNROLL];
+                {
+                  MvFields ma[UNROLL], mb[UNROLL];     // two half steps: records in stream order within each load
 #pragma unroll
-                for (int u = 0; u < UNROLL; ++u) {
-                  qe[2 * u] = vote<FB, MODE, SPILL>(decode((u32x2){cur[u].x, cur[u].y}), k, t0, t1, cnt, sq);
-                  qe[2 * u + 1] = vote<FB, MODE, SPILL>(decode((u32x2){cur[u].z, cur[u].w}), k, t0, t1, cnt, sq);
+                  for (int u = 0; u < UNROLL; ++u) {
+                    ma[u] = decode((u32x2){cur[u].x, cur[u].y});
+                    mb[u] = decode((u32x2){cur[u].z, cur[u].w});
+                  }
+                  vote_records<FB, MODE, SPILL, BATCH, true, DROP, UNROLL, (VAR & (512 | 1024 | 4096 | 8192))>(ma, k, t0, t1, cnt, sq);
+                  vote_records<FB, MODE, SPILL, BATCH, true, DROP, UNROLL, (VAR & (512 | 1024 | 4096 | 8192))>(mb, k, t0, t1, cnt, sq);
                 }
-#pragma unroll
-                for (int u = 0; u < 2 * UNROLL; ++u) queue_store<DROP>(sq, qe[u]);
                 p = j;
                 if (!more) break;
 #pragma unroll
@@ -565,10 +724,21 @@ __device__ __forceinline__ void scan_item(
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) d[u] = load_pair<VAR>(pbase + (p + (unsigned long long)u * BLOCK) * 16ull);
             __builtin_amdgcn_sched_barrier(0);   // every load of the step is issued before the first one is consumed
+            if constexpr (BATCH && MODE == MODE_UNARY && FB >= 2) {
+              MvFields ma[UNROLL], mb[UNROLL];
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
-              vote_now<FB, MODE, SPILL, DROP>(decode((u32x2){d[u].x, d[u].y}), k, t0, t1, cnt, sq);
-              vote_now<FB, MODE, SPILL, DROP>(decode((u32x2){d[u].z, d[u].w}), k, t0, t1, cnt, sq);
+              for (int u = 0; u < UNROLL; ++u) {
+                ma[u] = decode((u32x2){d[u].x, d[u].y});
+                mb[u] = decode((u32x2){d[u].z, d[u].w});
+              }
+              vote_records<FB, MODE, SPILL, BATCH, DEFER, DROP, UNROLL, (VAR & (512 | 1024 | 4096 | 8192))>(ma, k, t0, t1, cnt, sq);
+              vote_records<FB, MODE, SPILL, BATCH, DEFER, DROP, UNROLL, (VAR & (512 | 1024 | 4096 | 8192))>(mb, k, t0, t1, cnt, sq);
+            } else {
+#pragma unroll
+              for (int u = 0; u < UNROLL; ++u) {
+                vote_now<FB, MODE, SPILL, DROP>(decode((u32x2){d[u].x, d[u].y}), k, t0, t1, cnt, sq);
+                vote_now<FB, MODE, SPILL, DROP>(decode((u32x2){d[u].z, d[u].w}), k, t0, t1, cnt, sq);
+              }
             }
           }
           {
@@ -610,15 +780,11 @@ __device__ __forceinline__ void scan_item(
 #pragma unroll
               for (int u = 0; u < UNROLL; ++u)
                 nxt[u] = load_rec<VAR, REC>(more ? base + (j + (unsigned long long)u * BLOCK) * REC : base);
-              if constexpr (DEFER) {
-                QEntry qe[UNROLL];
+              {
+                MvFields mm[UNROLL];
 #pragma unroll
-                for (int u = 0; u < UNROLL; ++u) qe[u] = vote<FB, MODE, SPILL>(decode(cur[u]), k, t0, t1, cnt, sq);
-#pragma unroll
-                for (int u = 0; u < UNROLL; ++u) queue_store<DROP>(sq, qe[u]);
-              } else {
-#pragma unroll
-                for (int u = 0; u < UNROLL; ++u) vote_now<FB, MODE, SPILL, DROP>(decode(cur[u]), k, t0, t1, cnt, sq);
+                for (int u = 0; u < UNROLL; ++u) mm[u] = decode(cur[u]);
+                vote_records<FB, MODE, SPILL, BATCH, DEFER, DROP, UNROLL, (VAR & (512 | 1024 | 4096 | 8192))>(mm, k, t0, t1, cnt, sq);
               }
               i = j;
               if (!more) break;
@@ -634,16 +800,10 @@ __device__ __forceinline__ void scan_item(
             for (int u = 0; u < UNROLL; ++u) d[u] = load_rec<VAR, REC>(base + (i + (unsigned long long)u * BLOCK) * REC);
             // (the scheduler sinks loads 2..UNROLL below the wait for load 1; forcing them up front with
             //  a sched_barrier measured -1..-2 % here, +7 % in the compact loop above: left as it is)
-            if constexpr (DEFER) {
-              QEntry qe[UNROLL];
+            MvFields mm[UNROLL];
 #pragma unroll
-              for (int u = 0; u < UNROLL; ++u) qe[u] = vote<FB, MODE, SPILL>(decode(d[u]), k, t0, t1, cnt, sq);
-#pragma unroll
-              for (int u = 0; u < UNROLL; ++u) queue_store<DROP>(sq, qe[u]);
-            } else {
-#pragma unroll
-              for (int u = 0; u < UNROLL; ++u) vote_now<FB, MODE, SPILL, DROP>(decode(d[u]), k, t0, t1, cnt, sq);
-            }
+            for (int u = 0; u < UNROLL; ++u) mm[u] = decode(d[u]);
+            vote_records<FB, MODE, SPILL, BATCH, DEFER, DROP, UNROLL, (VAR & (512 | 1024 | 4096 | 8192))>(mm, k, t0, t1, cnt, sq);
           }
         }
         if (i < n) {
@@ -687,7 +847,7 @@ __device__ __forceinline__ void scan_item(
       // queue stores of every wave have left the CU before any wave of this workgroup replays them
       if constexpr (SPILL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {                                   // replay the votes band 0 queued for later bands
-      const unsigned int nq = *sq.tail;
+      const unsigned int nq = (VAR & 2048) != 0 ? 0u : *sq.tail;      // (2048: ablation, experiments build — no replay)
       unsigned int i = (unsigned int)tid;
       if constexpr (DEEP) {
         for (; i + 7u * BLOCK < nq; i += 8u * BLOCK) {
@@ -1033,11 +1193,15 @@ constexpr int SPILL_VAR = 0;
 #ifdef MTGPU_EXPERIMENTS
 template <int BLOCK>
 static hipError_t launch_spill_variant(const ScanLaunch &L) {
-  switch (L.variant & (8 | 16 | 32 | 64)) {
+  switch (L.variant & (8 | 16 | 32 | 64 | 256 | 512 | 1024 | 2048 | 4096 | 8192)) {
 #define MT_SPILL_CASE(v) case v: return launch_one<BLOCK, 4, MODE_UNARY, 40, true, 4, (v)>(L);
-    MT_SPILL_CASE(0) MT_SPILL_CASE(8) MT_SPILL_CASE(16) MT_SPILL_CASE(24) MT_SPILL_CASE(32) MT_SPILL_CASE(40)
-    MT_SPILL_CASE(48) MT_SPILL_CASE(56) MT_SPILL_CASE(64) MT_SPILL_CASE(72) MT_SPILL_CASE(80) MT_SPILL_CASE(88)
-    MT_SPILL_CASE(96) MT_SPILL_CASE(104) MT_SPILL_CASE(112) MT_SPILL_CASE(120)
+    MT_SPILL_CASE(0) MT_SPILL_CASE(8) MT_SPILL_CASE(16) MT_SPILL_CASE(24) MT_SPILL_CASE(56) MT_SPILL_CASE(64)
+    MT_SPILL_CASE(256) MT_SPILL_CASE(256 + 8) MT_SPILL_CASE(256 + 32) MT_SPILL_CASE(256 + 8 + 32) MT_SPILL_CASE(256 + 64)
+    MT_SPILL_CASE(256 + 8 + 32 + 64)
+    // ablations (wrong answers, timing only): no queue store / no LDS vote / no replay
+    MT_SPILL_CASE(256 + 32 + 512) MT_SPILL_CASE(256 + 32 + 1024) MT_SPILL_CASE(256 + 32 + 2048) MT_SPILL_CASE(256 + 32 + 512 + 2048)
+    MT_SPILL_CASE(256 + 32 + 512 + 1024 + 2048) MT_SPILL_CASE(256 + 32 + 1024 + 2048)
+    MT_SPILL_CASE(256 + 32 + 4096) MT_SPILL_CASE(256 + 32 + 8192) MT_SPILL_CASE(256 + 32 + 4096 + 8192)   // store flavour: nt / sc1 / both
 #undef MT_SPILL_CASE
     default: return hipErrorInvalidValue;
   }
