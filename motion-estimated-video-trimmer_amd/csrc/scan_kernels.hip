@@ -289,38 +289,69 @@ __device__ __forceinline__ void store_flag(unsigned char *flags, unsigned int f,
   __hip_atomic_store(&flags[f], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// Where a spilling workgroup (SPILL) keeps the votes later bands need.
+// Where a spilling workgroup (SPILL) keeps the votes later bands need: the frame's queue, one dword per record of the
+// frame, filled from both ends —
+//   singles  from the BACK, one dword per vote (or run of same-cell votes): (run - 1) << 30 | gy << 15 | gx
+//   spans    from the FRONT, two dwords for a whole wave instruction whose queued votes fall into CONSECUTIVE cells of
+//            one grid row, all with the same run length except possibly the first and the last cell (a block's
+//            records cut by the edge of the wave instruction) — what raster-ordered records produce wherever motion
+//            is dense:  {(run - 1) << 30 | gy << 15 | gx of the first cell,
+//                        cells | (first run - 1) << 8 | (last run - 1) << 10}
+// Round 5 measured what vote-heavy input costs on banded plans (profiles/r05_ab_spill_3_ablations.log): not the votes
+// (LDS votes removed: no change), not the replay (3 %), but the queue's STORES — 1-5 % of extra write traffic into a
+// saturated read stream cost 8-11 % of its rate, whatever their cache policy, order or instruction form.  A span entry
+// is 8 bytes where the same votes took up to 256: the queue of a frame in which every record votes shrinks 32-fold
+// (one record per cell) or 8-fold (four per cell).  A span covers >= 3 votes, so the two ends never meet.
 struct SpillQ {
-  unsigned int *q;        // this frame's queue: one slot per record of the frame
-  unsigned int *tail;     // entries so far (LDS)
+  unsigned int *q;        // this frame's queue: n dwords
+  unsigned int n;         // its size in dwords (records of the frame, at most 2^32 - 1)
+  unsigned int *tail;     // LDS: tail[0] singles so far (dwords from the back), tail[1] span dwords so far (from the front)
   int q_lo;               // first grid row a later band tracks (band 0's last centre row)
-  __amdgpu_buffer_rsrc_t rsrc;   // the same queue as a raw buffer (4 bytes per record of the frame): a store beyond it is
-                                 // DROPPED by the hardware.  Byte offsets are 32-bit: DROP kernels are launched only for
-                                 // batches of fewer than 2^30 records (launch_form), so that every frame fits
 };
 
-// What one lane appends to the frame's queue for one record: byte offset of its slot (NO_SLOT: nothing) and the entry.
-struct QEntry { unsigned int off, e; };
-constexpr unsigned int NO_SLOT = 0xffffffffu;
-
-// Queue stores.  PLAIN: a store under a branch per record (lanes without an entry skip it).  With such branches
-// between the loads of a step the compiler can no longer count which vector-memory operations are pending (a store may
-// or may not have been issued), takes the smaller count and so makes the wave wait for the ACK of the stores it just
-// issued before it may use the next load of the same step — a store round trip per step, serialised with the loads.
-// DROP: every lane stores, lanes without an entry at an offset beyond the buffer, where the hardware discards the
-// store: no branch, exact counts, and a wave never waits for a queue store (only before the replay, vmcnt(0)).
-template <bool DROP, int AUX = 0>
-__device__ __forceinline__ void queue_store(const SpillQ &sq, const QEntry qe) {
-  if constexpr (DROP) __builtin_amdgcn_raw_buffer_store_b32(qe.e, sq.rsrc, qe.off, 0, AUX);   // AUX: 1 sc0, 2 nt, 16 sc1
-  else if (qe.off != NO_SLOT) sq.q[qe.off >> 2] = qe.e;
+// `r` votes for each of the cells [c0, c0 + n) of the tile (consecutive cells of one row: a replayed span).  Thermometer
+// fields: a counter WORD at a time — one look, the next clear bits of every field of the word in ONE returning OR
+// (8 cells of a 4-bit form), and only the votes that lost a race to another wave settle cell by cell; other forms
+// cell by cell.
+template <int FB, int MODE>
+__device__ __forceinline__ void bump_cells(unsigned int *cnt, unsigned int c0, unsigned int n, unsigned int r, unsigned int cap) {
+  if constexpr (MODE == MODE_UNARY && FB >= 2 && FB <= 8) {
+    constexpr unsigned int CPW = 32u / FB, FM = (1u << FB) - 1u;
+    const unsigned int rr = r < cap ? r : cap;
+    unsigned int c = c0;
+    const unsigned int end = c0 + n;
+    while (c < end) {
+      const unsigned int wi = c / CPW, lo = c - wi * CPW, hi = min(CPW, end - wi * CPW);
+      const unsigned int x = cnt[wi];
+      unsigned int m = 0u;
+#pragma unroll
+      for (unsigned int q = 0; q < CPW; ++q) {
+        const unsigned int j = (unsigned int)__popc((x >> (q * FB)) & FM);
+        const unsigned int take = (q >= lo && q < hi && j < cap) ? min(rr, cap - j) : 0u;
+        m |= (((1u << take) - 1u) << j) << (q * FB);
+      }
+      if (m != 0u) {
+        const unsigned int lost = m & atomicOr(&cnt[wi], m);       // bits somebody else set between look and OR
+        if (lost != 0u) {
+#pragma unroll
+          for (unsigned int q = 0; q < CPW; ++q) {
+            const unsigned int l = (unsigned int)__popc((lost >> (q * FB)) & FM);
+            if (l != 0u) bump_n<FB, MODE>(cnt, wi * CPW + q, l, cap);
+          }
+        }
+      }
+      c = wi * CPW + hi;
+    }
+  } else {
+    for (unsigned int c = 0; c < n; ++c) bump_n<FB, MODE>(cnt, c0 + c, r, cap);
+  }
 }
 
 // Threshold + cell mapping + vote for one record (src/motion_scanner.cpp:246-267).
 // [t0,t1) = grid rows this tile tracks.
 template <int FB, int MODE, bool SPILL>
-__device__ __forceinline__ QEntry vote(const MvFields m, const ScanK &k, int t0, int t1,
-                                       unsigned int *cnt, const SpillQ &sq) {
-  QEntry qe = {NO_SLOT, 0u};
+__device__ __forceinline__ void vote(const MvFields m, const ScanK &k, int t0, int t1,
+                                     unsigned int *cnt, const SpillQ &sq) {
   const unsigned int dx = (unsigned int)(m.dst_x - m.src_x);   // |dx| <= 65535
   const unsigned int dy = (unsigned int)(m.dst_y - m.src_y);
   // dx*dx < 2^32 exactly; the sum needs 34 bits.  (The compiler proves the operands fit 17 bits and already
@@ -336,7 +367,6 @@ __device__ __forceinline__ QEntry vote(const MvFields m, const ScanK &k, int t0,
   if constexpr (!SPILL && (MODE == MODE_ADD32 || (MODE == MODE_UNARY && FB == 1))) {
     // fire-and-forget LDS atomics (32-bit add, 1-bit or): a single tile tracks every analysed row
     if (in) bump<FB, MODE>(cnt, (unsigned int)((gy - t0) * k.gw + gx), k.vec_need);
-    return qe;
   } else {
     // Returning LDS atomics (thermometer / CAS fields) and the spill queue: RUNS of records that one wave
     // instruction maps to the same cell — codecs export several vectors per block (two prediction directions,
@@ -344,7 +374,7 @@ __device__ __forceinline__ QEntry vote(const MvFields m, const ScanK &k, int t0,
     // records of a block otherwise queue up on ONE LDS word four times over (8 cells of a 4-bit form share a
     // word), and each would append its own queue entry.  A wave instruction without a voter costs one ballot.
     const unsigned long long any = __ballot(in);
-    if (any == 0ull) return qe;
+    if (any == 0ull) return;
     const int lane = (int)(threadIdx.x & 63u);
     const unsigned int key = in ? (((unsigned int)gy << 15) | (unsigned int)gx) : 0xffffffffu;   // gx, gy < 32768
     const unsigned int prev = (unsigned int)__shfl_up((int)key, 1);
@@ -362,186 +392,44 @@ __device__ __forceinline__ QEntry vote(const MvFields m, const ScanK &k, int t0,
     if constexpr (SPILL) mine = mine & ((unsigned int)(gy - t0) < (unsigned int)(t1 - t0));
     if (mine) bump_n<FB, MODE>(cnt, (unsigned int)((gy - t0) * k.gw + gx), run, k.vec_need);
     if constexpr (SPILL) {
-      // wave-aggregated append: one returning LDS add per wave instruction, contiguous stores;
-      // entry = (run - 1) << 30 | gy << 15 | gx
+      // wave-aggregated append (see SpillQ): one returning LDS add per wave instruction
       const bool qv = in & head & (gy >= sq.q_lo);
       const unsigned long long qm = __ballot(qv);
       if (qm != 0ull) {
         const int leader = __ffsll((long long)qm) - 1;
+        const unsigned int nq = (unsigned int)__popcll(qm);
+        const unsigned int rank = (unsigned int)__popcll(qm & ((1ull << lane) - 1ull));   // queued votes below this lane
+        const unsigned int r4 = min(run, 4u) - 1u;
+        const unsigned int e = (r4 << 30) | key;
+        // a span: the queued votes of this wave instruction are cells c, c + 1, c + 2, ... of one row (the keys then
+        // differ by exactly 1 from vote to vote: gy << 15 | gx with gx < 32768) and their runs are equally long
+        bool span = false;
+        unsigned int hdr0 = 0u, hdr1 = 0u;
+        if (nq >= 3u) {                                           // (wave-uniform)
+          const unsigned long long rest = qm & (qm - 1ull);       // without the first queued lane
+          const int second = __ffsll((long long)rest) - 1, last = 63 - __clzll((long long)qm);
+          const unsigned int key0 = (unsigned int)__builtin_amdgcn_readlane((int)key, leader);
+          const unsigned int rf = (unsigned int)__builtin_amdgcn_readlane((int)r4, leader);
+          const unsigned int rm = (unsigned int)__builtin_amdgcn_readlane((int)r4, second);
+          const unsigned int rl = (unsigned int)__builtin_amdgcn_readlane((int)r4, last);
+          span = __ballot(qv && ((key - rank != key0) || (lane != leader && lane != last && r4 != rm))) == 0ull;
+          hdr0 = (rm << 30) | key0;
+          hdr1 = nq | (rf << 8) | (rl << 10);
+        }
         unsigned int base = 0u;
-        if (lane == leader) base = atomicAdd(sq.tail, (unsigned int)__popcll(qm));
-        base = (unsigned int)__shfl((int)base, leader);
-        if (qv) {
-          qe.off = (base + (unsigned int)__popcll(qm & ((1ull << lane) - 1ull))) << 2;
-          qe.e = ((min(run, 4u) - 1u) << 30) | key;
+        if (lane == leader) base = atomicAdd(span ? sq.tail + 1 : sq.tail, span ? 2u : nq);
+        base = (unsigned int)__builtin_amdgcn_readlane((int)base, leader);
+        if (span) {
+          if (lane == leader) {
+            sq.q[base] = hdr0;
+            sq.q[base + 1u] = hdr1;
+          }
+        } else if (qv) {
+          sq.q[sq.n - 1u - (base + rank)] = e;
         }
       }
     }
-    return qe;
   }
-}
-
-// Lane l reads lane l-1's value (lane 0: `fill`): one DPP move inside the VALU (wave_shr:1, gfx9 family), where
-// __shfl_up goes through the LDS crossbar (ds_bpermute_b32: an LDS-pipe instruction and a wait).  Full EXEC only.
-__device__ __forceinline__ unsigned int from_lane_below(unsigned int v, unsigned int fill) {
-  return (unsigned int)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-}
-
-// The votes of one streaming STEP — U records per lane, every lane of the wave active — for thermometer fields
-// (MODE_UNARY, FB >= 2), with the same final counter state and the same queue entries (in the same order) as U calls
-// of vote().  vote() handles a record from its load to its queue slot before the next one starts: per record a
-// crossbar shuffle, a look at the field, a returning OR, a returning add on the queue tail, a second shuffle — five
-// LDS-pipe round trips, each waited for, 146 instructions; on input where every record votes that chain, not memory,
-// is what a wave spends its life in (round 4: 0.65-0.75 of the roofline on banded plans).  Here the U records move
-// through each stage together: U looks in flight, then U ORs in flight, ONE add on the queue tail for the whole step,
-// DPP / readfirstlane in place of the shuffles.  Votes that lose a race (another wave set the bit between look and
-// OR) settle in the same retry loop as bump_n.  A step in which no lane votes costs U ballots.
-template <int FB, int MODE, bool SPILL, int U, int ABL = 0>
-__device__ __forceinline__ void vote_step(const MvFields (&m)[U], const ScanK &k, int t0, int t1, unsigned int *cnt,
-                                          const SpillQ &sq, QEntry (&qe)[U]) {
-  static_assert(MODE == MODE_UNARY && FB >= 2 && FB <= 8, "thermometer fields only");
-  constexpr unsigned int FM = (1u << FB) - 1u;
-  const unsigned int lane = threadIdx.x & 63u;
-  bool in[U];
-  unsigned int key[U];
-  int gy[U];
-  unsigned long long any = 0ull;
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const unsigned int dx = (unsigned int)(m[u].dst_x - m[u].src_x), dy = (unsigned int)(m[u].dst_y - m[u].src_y);
-    const unsigned long long mag = (unsigned long long)(dx * dx) + (unsigned long long)(dy * dy);   // see vote()
-    const int gx = m[u].dst_x >> k.shift;
-    gy[u] = m[u].dst_y >> k.shift;
-    in[u] = (mag >= k.thr) & ((unsigned int)gx < (unsigned int)k.gw) &
-            ((unsigned int)(gy[u] - k.y_lo) < (unsigned int)(k.y_hi - k.y_lo));
-    key[u] = in[u] ? (((unsigned int)gy[u] << 15) | (unsigned int)gx) : 0xffffffffu;
-    any |= __ballot(in[u]);
-    qe[u].off = NO_SLOT;
-    qe[u].e = 0u;
-  }
-  if (any == 0ull) return;
-  // runs of equal cells inside each wave instruction (see vote(): same cut rules, every lane is active here)
-  const unsigned long long forced = (k.vec_need > 4u) ? 0x1111111111111111ull : 1ull;
-  bool head[U];
-  unsigned int run[U];
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const unsigned int prev = from_lane_below(key[u], ~key[u]);
-    const unsigned long long heads = __ballot(key[u] != prev) | forced;
-    head[u] = ((heads >> lane) & 1ull) != 0ull;
-    const unsigned long long above = (lane < 63u) ? (heads >> (lane + 1u)) : 0ull;
-    run[u] = above ? (unsigned int)__ffsll((long long)above) : (64u - lane);
-  }
-  // stage 1: the looks, all in flight
-  bool mine[U];
-  unsigned int *w[U];
-  unsigned int sh[U], f[U];
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    mine[u] = in[u] & head[u];
-    if constexpr (SPILL) mine[u] = mine[u] & ((unsigned int)(gy[u] - t0) < (unsigned int)(t1 - t0));
-    const unsigned int cell = mine[u] ? (unsigned int)((gy[u] - t0) * k.gw + (int)(key[u] & 0x7fffu)) : 0u;
-    const unsigned int bit = cell * (unsigned int)FB;
-    w[u] = &cnt[bit >> 5];
-    sh[u] = bit & 31u;
-    f[u] = 0u;
-  }
-  if constexpr ((ABL & 1024) != 0) {                      // ablation (experiments build): no LDS votes
-#pragma unroll
-    for (int u = 0; u < U; ++u) mine[u] = false;
-  }
-#pragma unroll
-  for (int u = 0; u < U; ++u)
-    if (mine[u]) f[u] = *w[u];
-  // stage 2: one returning OR each, all in flight
-  unsigned int left[U], j[U], mk[U], fo[U];
-  bool act[U];
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    j[u] = (unsigned int)__popc((f[u] >> sh[u]) & FM);
-    left[u] = min(run[u], k.vec_need);
-    act[u] = mine[u] & (j[u] < k.vec_need) & (left[u] != 0u);
-    const unsigned int take = min(left[u], k.vec_need - min(j[u], k.vec_need));
-    mk[u] = ((1u << take) - 1u) << j[u];
-    fo[u] = 0u;
-  }
-#pragma unroll
-  for (int u = 0; u < U; ++u)
-    if (act[u]) fo[u] = (atomicOr(w[u], mk[u] << sh[u]) >> sh[u]) & FM;
-  // stage 3: bits somebody else set between look and OR do not count for this lane: it continues above them
-#pragma unroll
-  for (int u = 0; u < U; ++u)
-    if (act[u]) {
-      unsigned int l = left[u] - (unsigned int)__popc(mk[u] & ~fo[u]);
-      unsigned int jj = (unsigned int)__popc(fo[u] | mk[u]);
-      while (l != 0u && jj < k.vec_need) {
-        const unsigned int take = min(l, k.vec_need - jj);
-        const unsigned int m2 = ((1u << take) - 1u) << jj;
-        const unsigned int o2 = (atomicOr(w[u], m2 << sh[u]) >> sh[u]) & FM;
-        l -= (unsigned int)__popc(m2 & ~o2);
-        jj = (unsigned int)__popc(o2 | m2);
-      }
-    }
-  if constexpr (SPILL) {
-    // the step's queue entries: one returning add on the tail for all of them, slots in record order
-    unsigned long long qm[U];
-    bool qv[U];
-    unsigned int total = 0u, before[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      qv[u] = in[u] & head[u] & (gy[u] >= sq.q_lo);
-      qm[u] = __ballot(qv[u]);
-      before[u] = total;
-      total += (unsigned int)__popcll(qm[u]);
-    }
-    if (total != 0u) {
-      unsigned int base = 0u;
-      if (lane == 0u) base = atomicAdd(sq.tail, total);
-      base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-        if (qv[u]) {
-          const unsigned int below = __builtin_amdgcn_mbcnt_hi((unsigned int)(qm[u] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)qm[u], 0u));
-          qe[u].off = (ABL & 512) != 0 ? NO_SLOT : (base + before[u] + below) << 2;    // ablation: nothing is stored
-          qe[u].e = ((min(run[u], 4u) - 1u) << 30) | key[u];
-        }
-    }
-  }
-}
-
-// One streaming step of U decoded records per lane (every lane active): batched (vote_step) where the counter form has
-// it and the build asks for it (STEP), else record by record; queue stores after the last vote (DEFER) or right away.
-template <int FB, int MODE, bool SPILL, bool STEP, bool DEFER, bool DROP, int U, int ABL = 0>
-__device__ __forceinline__ void vote_records(const MvFields (&m)[U], const ScanK &k, int t0, int t1, unsigned int *cnt,
-                                             const SpillQ &sq) {
-  if constexpr (STEP && MODE == MODE_UNARY && FB >= 2) {
-    QEntry qe[U];
-    vote_step<FB, MODE, SPILL, U, ABL>(m, k, t0, t1, cnt, sq, qe);
-    if constexpr (SPILL) {
-#pragma unroll
-      for (int u = 0; u < U; ++u) queue_store<DROP, ((ABL & 4096) ? 2 : 0) | ((ABL & 8192) ? 16 : 0)>(sq, qe[u]);
-    }
-  } else if constexpr (SPILL && DEFER) {
-    QEntry qe[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) qe[u] = vote<FB, MODE, SPILL>(m[u], k, t0, t1, cnt, sq);
-#pragma unroll
-    for (int u = 0; u < U; ++u) queue_store<DROP>(sq, qe[u]);
-  } else {
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const QEntry qe = vote<FB, MODE, SPILL>(m[u], k, t0, t1, cnt, sq);
-      if constexpr (SPILL) queue_store<DROP>(sq, qe);
-    }
-  }
-}
-
-// vote + the queue store right behind it (head records, tails, pre-issued steps: outside the streaming loop)
-template <int FB, int MODE, bool SPILL, bool DROP>
-__device__ __forceinline__ void vote_now(const MvFields m, const ScanK &k, int t0, int t1, unsigned int *cnt,
-                                         const SpillQ &sq) {
-  const QEntry qe = vote<FB, MODE, SPILL>(m, k, t0, t1, cnt, sq);
-  if constexpr (SPILL) queue_store<DROP>(sq, qe);
 }
 
 // Compact records: how many records at the start of a frame's array are scanned one by one so that the
@@ -573,16 +461,6 @@ __device__ __forceinline__ void scan_item(
     unsigned int *spill_q, unsigned int *slice_ws, unsigned int *tickets, unsigned int *lds,
     NextStep<UNROLL> &ns, const bool has_next) {
   typedef typename RawOf<REC>::type Raw;
-  // Banded plans (SPILL), how the queue is written — VAR bits, chosen per build by launch_form:
-  //   16 DEFER  the queue stores of a streaming step are issued after the step's last vote, not between its loads
-  //    8 PIPE   the next step's loads are issued before this step's votes (software pipelining)
-  //   32 DROP   branch-free stores: lanes without an entry store beyond the buffer (queue_store)
-  //   64 DEEP   the replay keeps 8 queue loads in flight per lane instead of 4
-  constexpr bool DROP = SPILL && (VAR & 32) != 0;
-  constexpr bool DEFER = SPILL && (VAR & 16) != 0;
-  constexpr bool DEEP = SPILL && (VAR & 64) != 0;
-  //  256 BATCH  the records of a streaming step vote together (vote_step: thermometer fields; any plan, banded or not)
-  constexpr bool BATCH = (VAR & 256) != 0;
   const int tid = threadIdx.x;
   // item -> frame, or (frame, slice): bands and slices are never both > 1
   PT_DECL;
@@ -617,9 +495,8 @@ __device__ __forceinline__ void scan_item(
   unsigned int *ticket = total + 1;
   SpillQ sq;
   sq.q = SPILL ? spill_q + q0 : nullptr;
-  sq.rsrc = __builtin_amdgcn_make_buffer_rsrc(SPILL ? (void *)(spill_q + q0) : (void *)lds, 0,
-                                              (DROP && (r1 - r0) < (1ull << 30)) ? (int)((r1 - r0) * 4ull) : 0, 0x00020000);
-  sq.tail = total + 2;
+  sq.n = (unsigned int)min(r1 - r0, 0xffffffffull);
+  sq.tail = total + 2;                                             // two words: singles, span dwords
   sq.q_lo = min(k.y_hi, k.y_lo + k.band_rows) - 1;                 // band 0's last centre row
 
   const int n_bands = SPILL ? k.bands : 1;
@@ -637,7 +514,7 @@ __device__ __forceinline__ void scan_item(
       u32x4 *c4 = reinterpret_cast<u32x4 *>(cnt);
       const int n4 = k.cnt_words >> 2;
       for (int i = tid; i < n4; i += BLOCK) c4[i] = (u32x4){0u, 0u, 0u, 0u};
-      if (band == 0 && tid == 0) { *total = 0u; *sq.tail = 0u; }
+      if (band == 0 && tid == 0) { *total = 0u; sq.tail[0] = 0u; sq.tail[1] = 0u; }
     }
     __syncthreads();
     PT_ADD(0);
@@ -659,7 +536,7 @@ __device__ __forceinline__ void scan_item(
             unsigned long long h = (unsigned long long)((13u * ((16u - (r >> 3)) & 15u)) & 15u);
             h = h < n ? h : n;
             if ((unsigned long long)tid < h)
-              vote_now<FB, MODE, SPILL, DROP>(decode(load_rec<VAR, REC>(base + (unsigned long long)tid * REC)), k, t0, t1, cnt, sq);
+              vote<FB, MODE, SPILL>(decode(load_rec<VAR, REC>(base + (unsigned long long)tid * REC)), k, t0, t1, cnt, sq);
             base += h * (unsigned long long)REC;
             n -= h;
           }
@@ -677,68 +554,28 @@ __device__ __forceinline__ void scan_item(
           const unsigned char *pbase = base + head * 8ull;
           const unsigned long long np = (n - head) >> 1;            // pairs
           if ((unsigned long long)tid < head)
-            vote_now<FB, MODE, SPILL, DROP>(decode(load_compact<VAR>(base + (unsigned long long)tid * 8ull)), k, t0, t1, cnt, sq);
+            vote<FB, MODE, SPILL>(decode(load_compact<VAR>(base + (unsigned long long)tid * 8ull)), k, t0, t1, cnt, sq);
           if (tid == 0 && ((n - head) & 1ull) != 0ull)
-            vote_now<FB, MODE, SPILL, DROP>(decode(load_compact<VAR>(base + (n - 1ull) * 8ull)), k, t0, t1, cnt, sq);
+            vote<FB, MODE, SPILL>(decode(load_compact<VAR>(base + (n - 1ull) * 8ull)), k, t0, t1, cnt, sq);
           unsigned long long p = tid;
           if (ns.have) {                       // this frame's first step (ns.frame == f, checked on entry) was issued during
             ns.have = false;                   // the previous frame's cluster test
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) {
-              vote_now<FB, MODE, SPILL, DROP>(decode((u32x2){ns.d[u].x, ns.d[u].y}), k, t0, t1, cnt, sq);
-              vote_now<FB, MODE, SPILL, DROP>(decode((u32x2){ns.d[u].z, ns.d[u].w}), k, t0, t1, cnt, sq);
+              vote<FB, MODE, SPILL>(decode((u32x2){ns.d[u].x, ns.d[u].y}), k, t0, t1, cnt, sq);
+              vote<FB, MODE, SPILL>(decode((u32x2){ns.d[u].z, ns.d[u].w}), k, t0, t1, cnt, sq);
             }
             p += STEP;
-          }
-          if constexpr (SPILL && (VAR & 8) != 0) {
-            // banded plans: software-pipelined, see the 40-byte loop below ("PIPE")
-            if (p + LAST < np) {
-              u32x4 cur[UNROLL], nxt[UNROLL];
-#pragma unroll
-              for (int u = 0; u < UNROLL; ++u) cur[u] = load_pair<VAR>(pbase + (p + (unsigned long long)u * BLOCK) * 16ull);
-              for (;;) {
-                const unsigned long long j = p + STEP;
-                const bool more = j + LAST < np;
-#pragma unroll
-                for (int u = 0; u < UNROLL; ++u)
-                  nxt[u] = load_pair<VAR>(more ? pbase + (j + (unsigned long long)u * BLOCK) * 16ull : pbase);
-                {
-                  MvFields ma[UNROLL], mb[UNROLL];     // two half steps: records in stream order within each load
-#pragma unroll
-                  for (int u = 0; u < UNROLL; ++u) {
-                    ma[u] = decode((u32x2){cur[u].x, cur[u].y});
-                    mb[u] = decode((u32x2){cur[u].z, cur[u].w});
-                  }
-                  vote_records<FB, MODE, SPILL, BATCH, true, DROP, UNROLL, (VAR & (512 | 1024 | 4096 | 8192))>(ma, k, t0, t1, cnt, sq);
-                  vote_records<FB, MODE, SPILL, BATCH, true, DROP, UNROLL, (VAR & (512 | 1024 | 4096 | 8192))>(mb, k, t0, t1, cnt, sq);
-                }
-                p = j;
-                if (!more) break;
-#pragma unroll
-                for (int u = 0; u < UNROLL; ++u) cur[u] = nxt[u];
-              }
-            }
           }
           for (; p + LAST < np; p += STEP) {
             u32x4 d[UNROLL];
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) d[u] = load_pair<VAR>(pbase + (p + (unsigned long long)u * BLOCK) * 16ull);
             __builtin_amdgcn_sched_barrier(0);   // every load of the step is issued before the first one is consumed
-            if constexpr (BATCH && MODE == MODE_UNARY && FB >= 2) {
-              MvFields ma[UNROLL], mb[UNROLL];
 #pragma unroll
-              for (int u = 0; u < UNROLL; ++u) {
-                ma[u] = decode((u32x2){d[u].x, d[u].y});
-                mb[u] = decode((u32x2){d[u].z, d[u].w});
-              }
-              vote_records<FB, MODE, SPILL, BATCH, DEFER, DROP, UNROLL, (VAR & (512 | 1024 | 4096 | 8192))>(ma, k, t0, t1, cnt, sq);
-              vote_records<FB, MODE, SPILL, BATCH, DEFER, DROP, UNROLL, (VAR & (512 | 1024 | 4096 | 8192))>(mb, k, t0, t1, cnt, sq);
-            } else {
-#pragma unroll
-              for (int u = 0; u < UNROLL; ++u) {
-                vote_now<FB, MODE, SPILL, DROP>(decode((u32x2){d[u].x, d[u].y}), k, t0, t1, cnt, sq);
-                vote_now<FB, MODE, SPILL, DROP>(decode((u32x2){d[u].z, d[u].w}), k, t0, t1, cnt, sq);
-              }
+            for (int u = 0; u < UNROLL; ++u) {
+              vote<FB, MODE, SPILL>(decode((u32x2){d[u].x, d[u].y}), k, t0, t1, cnt, sq);
+              vote<FB, MODE, SPILL>(decode((u32x2){d[u].z, d[u].w}), k, t0, t1, cnt, sq);
             }
           }
           {
@@ -755,42 +592,34 @@ __device__ __forceinline__ void scan_item(
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u)
               if (ok[u]) {
-                vote_now<FB, MODE, SPILL, DROP>(decode((u32x2){d[u].x, d[u].y}), k, t0, t1, cnt, sq);
-                vote_now<FB, MODE, SPILL, DROP>(decode((u32x2){d[u].z, d[u].w}), k, t0, t1, cnt, sq);
+                vote<FB, MODE, SPILL>(decode((u32x2){d[u].x, d[u].y}), k, t0, t1, cnt, sq);
+                vote<FB, MODE, SPILL>(decode((u32x2){d[u].z, d[u].w}), k, t0, t1, cnt, sq);
               }
           }
           i = n;                                                    // nothing left for the generic tail loop
         } else if constexpr ((VAR & 8) != 0) {
-          // PIPE — software-pipelined: the next step's loads are issued before this step is consumed, so a wave that
-          // votes (returning LDS atomics: dependent round trips) keeps its loads in flight meanwhile.  Two details
-          // decide whether that works at all, both about how the compiler counts pending vector-memory operations
-          // (s_waitcnt vmcnt is a static number, the minimum over every path that reaches it):
-          //  - the prefetch is UNCONDITIONAL: after the last full step it reads one dummy address (the frame's first
-          //    bytes, one line per wave instruction) instead of being skipped — under `if (more)` the compiler must
-          //    assume the loads were not issued and waits for them before it lets the current step be used (round 4
-          //    measured exactly that form as "no gain");
-          //  - queue stores are issued after the step's last vote (DEFER) and, with DROP, without a branch.
-          if (i + LAST < n) {
-            Raw cur[UNROLL], nxt[UNROLL];
+          // software-pipelined: the next batch of loads is issued before this batch is consumed
+          Raw cur[UNROLL], nxt[UNROLL];
+          bool have = i + LAST < n;
+          if (have) {
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) cur[u] = load_rec<VAR, REC>(base + (i + (unsigned long long)u * BLOCK) * REC);
-            for (;;) {
-              const unsigned long long j = i + STEP;
-              const bool more = j + LAST < n;
+          }
+          while (have) {
+            const unsigned long long j = i + STEP;
+            const bool more = j + LAST < n;
+            if (more) {
 #pragma unroll
-              for (int u = 0; u < UNROLL; ++u)
-                nxt[u] = load_rec<VAR, REC>(more ? base + (j + (unsigned long long)u * BLOCK) * REC : base);
-              {
-                MvFields mm[UNROLL];
+              for (int u = 0; u < UNROLL; ++u) nxt[u] = load_rec<VAR, REC>(base + (j + (unsigned long long)u * BLOCK) * REC);
+            }
 #pragma unroll
-                for (int u = 0; u < UNROLL; ++u) mm[u] = decode(cur[u]);
-                vote_records<FB, MODE, SPILL, BATCH, DEFER, DROP, UNROLL, (VAR & (512 | 1024 | 4096 | 8192))>(mm, k, t0, t1, cnt, sq);
-              }
-              i = j;
-              if (!more) break;
+            for (int u = 0; u < UNROLL; ++u) vote<FB, MODE, SPILL>(decode(cur[u]), k, t0, t1, cnt, sq);
+            if (more) {
 #pragma unroll
               for (int u = 0; u < UNROLL; ++u) cur[u] = nxt[u];
             }
+            i = j;
+            have = more;
           }
         } else {
           // main body: UNROLL independent loads in flight per lane
@@ -800,10 +629,8 @@ __device__ __forceinline__ void scan_item(
             for (int u = 0; u < UNROLL; ++u) d[u] = load_rec<VAR, REC>(base + (i + (unsigned long long)u * BLOCK) * REC);
             // (the scheduler sinks loads 2..UNROLL below the wait for load 1; forcing them up front with
             //  a sched_barrier measured -1..-2 % here, +7 % in the compact loop above: left as it is)
-            MvFields mm[UNROLL];
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) mm[u] = decode(d[u]);
-            vote_records<FB, MODE, SPILL, BATCH, DEFER, DROP, UNROLL, (VAR & (512 | 1024 | 4096 | 8192))>(mm, k, t0, t1, cnt, sq);
+            for (int u = 0; u < UNROLL; ++u) vote<FB, MODE, SPILL>(decode(d[u]), k, t0, t1, cnt, sq);
           }
         }
         if (i < n) {
@@ -820,7 +647,7 @@ __device__ __forceinline__ void scan_item(
           }
 #pragma unroll
           for (int u = 0; u < TU; ++u)
-            if (ok[u]) vote_now<FB, MODE, SPILL, DROP>(decode(d[u]), k, t0, t1, cnt, sq);
+            if (ok[u]) vote<FB, MODE, SPILL>(decode(d[u]), k, t0, t1, cnt, sq);
         }
       }
       if constexpr (REC == 8 && !SPILL) {
@@ -847,24 +674,14 @@ __device__ __forceinline__ void scan_item(
       // queue stores of every wave have left the CU before any wave of this workgroup replays them
       if constexpr (SPILL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {                                   // replay the votes band 0 queued for later bands
-      const unsigned int nq = (VAR & 2048) != 0 ? 0u : *sq.tail;      // (2048: ablation, experiments build — no replay)
+      // singles (from the back of the queue): one entry per lane, four loads in flight
+      const unsigned int nq = sq.tail[0];
+      const unsigned int *qs = sq.q + (sq.n - nq);       // entries nq-1 .. 0 in ascending address order
       unsigned int i = (unsigned int)tid;
-      if constexpr (DEEP) {
-        for (; i + 7u * BLOCK < nq; i += 8u * BLOCK) {
-          unsigned int e[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) e[u] = sq.q[i + (unsigned int)u * BLOCK];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const int gy = (int)((e[u] >> 15) & 0x7fffu), gx = (int)(e[u] & 0x7fffu);
-            if (gy >= t0 && gy < t1) bump_n<FB, MODE>(cnt, (unsigned int)((gy - t0) * k.gw + gx), (e[u] >> 30) + 1u, k.vec_need);
-          }
-        }
-      }
       for (; i + 3u * BLOCK < nq; i += 4u * BLOCK) {
         unsigned int e[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) e[u] = sq.q[i + (unsigned int)u * BLOCK];
+        for (int u = 0; u < 4; ++u) e[u] = qs[i + (unsigned int)u * BLOCK];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int gy = (int)((e[u] >> 15) & 0x7fffu), gx = (int)(e[u] & 0x7fffu);
@@ -872,9 +689,29 @@ __device__ __forceinline__ void scan_item(
         }
       }
       for (; i < nq; i += BLOCK) {
-        const unsigned int e = sq.q[i];
+        const unsigned int e = qs[i];
         const int gy = (int)((e >> 15) & 0x7fffu), gx = (int)(e & 0x7fffu);
         if (gy >= t0 && gy < t1) bump_n<FB, MODE>(cnt, (unsigned int)((gy - t0) * k.gw + gx), (e >> 30) + 1u, k.vec_need);
+      }
+      // spans (from the front): one span per LANE, which walks the span's cells.  Neighbouring lanes then vote in
+      // different rows / far-apart columns — different LDS words — where the cells of ONE span share words (8 cells of
+      // a 4-bit form to a word): no same-word serialisation of the returning ORs, and 64 spans in flight per wave.
+      const unsigned int nspans = sq.tail[1] >> 1;
+      unsigned int sp = (unsigned int)tid;
+      bool have = sp < nspans;
+      unsigned int h0 = have ? sq.q[2u * sp] : 0u, h1 = have ? sq.q[2u * sp + 1u] : 0u;
+      while (have) {
+        const unsigned int nx = sp + BLOCK;                // the next header is on its way while this span votes
+        const bool more = nx < nspans;
+        const unsigned int n0 = more ? sq.q[2u * nx] : 0u, n1 = more ? sq.q[2u * nx + 1u] : 0u;
+        const int gy = (int)((h0 >> 15) & 0x7fffu), gx = (int)(h0 & 0x7fffu);
+        if (gy >= t0 && gy < t1) {
+          const unsigned int cell0 = (unsigned int)((gy - t0) * k.gw + gx), len = h1 & 0xffu;      // len >= 3
+          bump_n<FB, MODE>(cnt, cell0, ((h1 >> 8) & 3u) + 1u, k.vec_need);                          // first cell: its own run
+          bump_cells<FB, MODE>(cnt, cell0 + 1u, len - 2u, (h0 >> 30) + 1u, k.vec_need);
+          bump_n<FB, MODE>(cnt, cell0 + len - 1u, ((h1 >> 10) & 3u) + 1u, k.vec_need);              // last cell: its own run
+        }
+        h0 = n0; h1 = n1; sp = nx; have = more;
       }
     }
     __syncthreads();
@@ -1185,56 +1022,16 @@ static hipError_t launch_variant(const ScanLaunch &L) {
 }
 #endif
 
-// How banded plans write and replay their queue (scan_item: DEFER / PIPE / DROP / DEEP).  One choice per build;
-// the experiments build can select any combination for the 4-bit thermometer form on 40-byte records
-// (MTGPU_VARIANT bits 8 | 16 | 32 | 64) to compare them in one process.
-constexpr int SPILL_VAR = 0;
-
-#ifdef MTGPU_EXPERIMENTS
-template <int BLOCK>
-static hipError_t launch_spill_variant(const ScanLaunch &L) {
-  switch (L.variant & (8 | 16 | 32 | 64 | 256 | 512 | 1024 | 2048 | 4096 | 8192)) {
-#define MT_SPILL_CASE(v) case v: return launch_one<BLOCK, 4, MODE_UNARY, 40, true, 4, (v)>(L);
-    MT_SPILL_CASE(0) MT_SPILL_CASE(8) MT_SPILL_CASE(16) MT_SPILL_CASE(24) MT_SPILL_CASE(56) MT_SPILL_CASE(64)
-    MT_SPILL_CASE(256) MT_SPILL_CASE(256 + 8) MT_SPILL_CASE(256 + 32) MT_SPILL_CASE(256 + 8 + 32) MT_SPILL_CASE(256 + 64)
-    MT_SPILL_CASE(256 + 8 + 32 + 64)
-    // ablations (wrong answers, timing only): no queue store / no LDS vote / no replay
-    MT_SPILL_CASE(256 + 32 + 512) MT_SPILL_CASE(256 + 32 + 1024) MT_SPILL_CASE(256 + 32 + 2048) MT_SPILL_CASE(256 + 32 + 512 + 2048)
-    MT_SPILL_CASE(256 + 32 + 512 + 1024 + 2048) MT_SPILL_CASE(256 + 32 + 1024 + 2048)
-    MT_SPILL_CASE(256 + 32 + 4096) MT_SPILL_CASE(256 + 32 + 8192) MT_SPILL_CASE(256 + 32 + 4096 + 8192)   // store flavour: nt / sc1 / both
-#undef MT_SPILL_CASE
-    default: return hipErrorInvalidValue;
-  }
-}
-#endif
-
-// One counter form of a plan.  Banded plans (SPILL) run the SPILL_VAR flavour of the queue code; its branch-free
-// DROP stores address the frame's queue with 32-bit byte offsets, so batches of 2^30 records and more (every frame
-// is then not known to fit) take the same kernel without DROP.
-template <int BLOCK, int FB, int MODE, int REC, bool SPILL>
-static hipError_t launch_counter_form(const ScanLaunch &L) {
-  if constexpr (SPILL) {
-    if (L.n_records < (1ull << 30)) return launch_one<BLOCK, FB, MODE, REC, true, 4, SPILL_VAR>(L);
-    return launch_one<BLOCK, FB, MODE, REC, true, 4, (SPILL_VAR & ~32)>(L);
-  } else {
-    return launch_one<BLOCK, FB, MODE, REC, false>(L);
-  }
-}
-
 template <int BLOCK, int REC, bool SPILL>
 static hipError_t launch_form(const ScanLaunch &L) {
   const int key = L.k.mode * 100 + L.k.fb;
-#ifdef MTGPU_EXPERIMENTS
-  if constexpr (SPILL && REC == 40 && BLOCK == 1024)
-    if (key == MODE_UNARY * 100 + 4 && (L.variant & 128) != 0) return launch_spill_variant<BLOCK>(L);
-#endif
   switch (key) {
-    case MODE_ADD32 * 100 + 32: return launch_counter_form<BLOCK, 32, MODE_ADD32, REC, SPILL>(L);
-    case MODE_UNARY * 100 + 1: return launch_counter_form<BLOCK, 1, MODE_UNARY, REC, SPILL>(L);
-    case MODE_UNARY * 100 + 2: return launch_counter_form<BLOCK, 2, MODE_UNARY, REC, SPILL>(L);
-    case MODE_UNARY * 100 + 4: return launch_counter_form<BLOCK, 4, MODE_UNARY, REC, SPILL>(L);
-    case MODE_UNARY * 100 + 8: return launch_counter_form<BLOCK, 8, MODE_UNARY, REC, SPILL>(L);
-    case MODE_CAS * 100 + 8: return launch_counter_form<BLOCK, 8, MODE_CAS, REC, SPILL>(L);
+    case MODE_ADD32 * 100 + 32: return launch_one<BLOCK, 32, MODE_ADD32, REC, SPILL>(L);
+    case MODE_UNARY * 100 + 1: return launch_one<BLOCK, 1, MODE_UNARY, REC, SPILL>(L);
+    case MODE_UNARY * 100 + 2: return launch_one<BLOCK, 2, MODE_UNARY, REC, SPILL>(L);
+    case MODE_UNARY * 100 + 4: return launch_one<BLOCK, 4, MODE_UNARY, REC, SPILL>(L);
+    case MODE_UNARY * 100 + 8: return launch_one<BLOCK, 8, MODE_UNARY, REC, SPILL>(L);
+    case MODE_CAS * 100 + 8: return launch_one<BLOCK, 8, MODE_CAS, REC, SPILL>(L);
     default: return hipErrorInvalidValue;
   }
 }
