@@ -29,9 +29,10 @@
  *  - pinned host memory ALLOCATED BY THE DRIVER — hipHostMalloc, any flags — through its device address
  *    (hipHostGetDevicePointer).  The pipe's zero-copy staging is exactly this: the kernel streams such memory over
  *    PCIe and writes its one result byte per frame into it.
- *  Every result byte is written once, by one lane, with a system-scope write-through store (no cache keeps the line),
- *  so `d_flags` may share its lines with nothing the HOST writes while the call is in flight — give it lines of its
- *  own (128-byte aligned) when it lives in host memory, as the pipe does.  Results in host memory are complete when
+ *  Every result byte is written once, by one lane; when `d_flags` is not device memory (the entry points ask the
+ *  runtime: hipPointerGetAttributes) with a system-scope write-through store, so that no cache keeps the line.
+ *  `d_flags` in host memory should share its lines with nothing the HOST writes while the call is in flight — give
+ *  it lines of its own (128-byte aligned), as the pipe does.  Results in host memory are complete when
  *  an event recorded behind the call on `stream` (hipEventReleaseToSystem) or a stream synchronisation has passed.
  *  NOT supported, and not checked: host memory page-locked with hipHostRegister (a user-pointer mapping: its pages
  *  are not pinned by the driver, the kernel driver re-validates the mapping when the OS touches them — the one wrong

@@ -18,7 +18,9 @@ hipStream_t ctx_pipe_stream(mtgpu_ctx *c);
 int physical_device(int logical);
 // Launch the scan for a device-resident batch on `st`.
 // rec_bytes: MT_MV_BYTES (AVMotionVector records) or MT_COMPACT_BYTES (packed src/dst fields).
+// flags_in_host_memory: d_flags is pinned host memory (zero-copy staging): result bytes are stored at system scope.
 int ctx_launch_scan(mtgpu_ctx *c, const void *d_mv, uint64_t n_records, const uint64_t *d_off,
-                    const uint8_t *d_sd, uint32_t n_frames, uint8_t *d_flags, hipStream_t st, int rec_bytes);
+                    const uint8_t *d_sd, uint32_t n_frames, uint8_t *d_flags, hipStream_t st, int rec_bytes,
+                    int flags_in_host_memory);
 
 }  // namespace mtgpu

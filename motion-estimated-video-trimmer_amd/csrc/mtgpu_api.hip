@@ -263,6 +263,7 @@ int make_plan(mtgpu_ctx *c, int lds_max, int cu_count) {
   }
   k.slices = 1;
   k.group = 1;
+  k.sys_flags = 0;                                            // per launch: launch_scan_on
   k.align_lines = exp_int("MTGPU_ALIGN", 1) != 0 ? 1 : 0;     // experiments: 0 = streams start wherever the frame starts
   k.prefetch = exp_int("MTGPU_PREFETCH", 1) != 0 ? 1 : 0;      // experiments: 0 switches the next-frame prefetch off
   c->group_request = env_int("MTGPU_GROUP", 0);
@@ -342,8 +343,18 @@ hipError_t scratch_alloc(mtgpu_ctx *c, void **p, size_t bytes, hipStream_t st) {
 
 // Launches the scan on `st`; scratch (band centre counts, slice tiles + tickets) is allocated
 // and freed stream-ordered, so concurrent callers share nothing.
+// flags_sys: 1 = d_flags is not device memory (system-scope result stores), 0 = device memory, -1 = ask the runtime
 int launch_scan_on(mtgpu_ctx *c, const void *d_mv, uint64_t n_records, const uint64_t *d_off,
-                   const uint8_t *d_sd, uint32_t n_frames, uint8_t *d_flags, hipStream_t st, int rec_bytes = MT_MV_BYTES) {
+                   const uint8_t *d_sd, uint32_t n_frames, uint8_t *d_flags, hipStream_t st, int rec_bytes = MT_MV_BYTES,
+                   int flags_sys = 0) {
+  if (flags_sys < 0) {
+    // a caller's pointer (the *_device entry points): device memory takes plain stores; anything else the runtime
+    // knows of, or does not know at all, takes the system-scope ones
+    hipPointerAttribute_t at;
+    std::memset(&at, 0, sizeof at);
+    flags_sys = (hipPointerGetAttributes(&at, d_flags) == hipSuccess && at.type == hipMemoryTypeDevice) ? 0 : 1;
+    (void)hipGetLastError();
+  }
   mtgpu::ScanLaunch L;
   L.rec_bytes = rec_bytes;
   L.lds_max = c->lds_max;
@@ -358,6 +369,7 @@ int launch_scan_on(mtgpu_ctx *c, const void *d_mv, uint64_t n_records, const uin
   L.slice_ws = nullptr;
   L.tickets = nullptr;
   L.k = c->k;
+  L.k.sys_flags = flags_sys;
   L.k.slices = choose_slices(c, n_records, n_frames);
   L.k.group = choose_group(c, n_records, n_frames, rec_bytes, L.k.slices);
   if ((uint64_t)n_frames * (uint64_t)L.k.slices >= (1ull << 32))
@@ -434,8 +446,8 @@ int physical_device(int logical) {
   return logical >= 0 ? logical % n : logical;
 }
 int ctx_launch_scan(mtgpu_ctx *c, const void *d_mv, uint64_t n_records, const uint64_t *d_off,
-                    const uint8_t *d_sd, uint32_t n_frames, uint8_t *d_flags, hipStream_t st, int rec_bytes) {
-  return launch_scan_on(c, d_mv, n_records, d_off, d_sd, n_frames, d_flags, st, rec_bytes);
+                    const uint8_t *d_sd, uint32_t n_frames, uint8_t *d_flags, hipStream_t st, int rec_bytes, int flags_in_host_memory) {
+  return launch_scan_on(c, d_mv, n_records, d_off, d_sd, n_frames, d_flags, st, rec_bytes, flags_in_host_memory ? 1 : 0);
 }
 }  // namespace mtgpu
 
@@ -655,7 +667,7 @@ int mtgpu_scan_frames_device(mtgpu_ctx *c, const void *d_mv, uint64_t n_records,
     if (rc != MT_OK) return rc;
   }
   return launch_scan_on(c, d_mv, n_records, d_frame_off, d_has_sd, n_frames, d_flags,
-                        static_cast<hipStream_t>(stream));
+                        static_cast<hipStream_t>(stream), MT_MV_BYTES, -1);
 }
 
 int mtgpu_scan_frames_device_compact(mtgpu_ctx *c, const void *d_rec8, uint64_t n_records,
@@ -672,7 +684,7 @@ int mtgpu_scan_frames_device_compact(mtgpu_ctx *c, const void *d_rec8, uint64_t 
     if (rc != MT_OK) return rc;
   }
   return launch_scan_on(c, d_rec8, n_records, d_frame_off, d_has_sd, n_frames, d_flags,
-                        static_cast<hipStream_t>(stream), MT_COMPACT_BYTES);
+                        static_cast<hipStream_t>(stream), MT_COMPACT_BYTES, -1);
 }
 
 int mtgpu_pack_records(const void *mv_bytes, uint64_t n_records, void *out8) {

@@ -367,7 +367,7 @@ int mtgpu_pipe_submit(mtgpu_pipe *p, mtgpu_batch *b) {
       goto bad;
     }
     rc = mtgpu::ctx_launch_scan(p->ctx, b->d_mv, b->n_records, b->d_off, b->d_sd, b->n_frames, b->d_flags, st,
-                                b->rec_bytes);
+                                b->rec_bytes, b->zero_copy ? 1 : 0);
     if (rc != MT_OK) goto bad;
     if (!b->zero_copy)
       PIPE_TRY(hipMemcpyAsync(b->h_flags, b->d_flags, b->n_frames, hipMemcpyDeviceToHost, st));

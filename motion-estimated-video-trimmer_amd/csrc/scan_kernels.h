@@ -28,6 +28,8 @@ struct ScanK {
   int group;               // consecutive work items per workgroup (>= 1; > 1 only with slices == 1)
   int align_lines;         // 40-byte records: peel < 16 head records so that the stream starts on a 128-byte line
   int prefetch;            // compact records, group > 1: issue the next frame's first step before this frame's cluster test
+  int sys_flags;           // flags do not live in device memory (pinned host memory: the pipe's zero-copy staging, a caller's
+                           // hipHostMalloc'ed buffer): result bytes leave with system-scope write-through stores
 };
 
 struct ScanLaunch {

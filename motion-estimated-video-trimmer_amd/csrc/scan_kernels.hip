@@ -280,13 +280,16 @@ __device__ __forceinline__ unsigned int combine_words(unsigned int a, unsigned i
   }
 }
 
-// The one result byte of a frame.  Written with a SYSTEM-scope store (global_store_byte ... sc0 sc1: write-through
-// past the XCD's L2, byte-masked): `flags` may be pinned host memory that the kernel writes over PCIe (the pipe's
-// zero-copy staging) next to bytes other workgroups — on other XCDs — write into the same line at other times, so
-// no cache on the way may hold the line and merge it back later.  On device memory the store costs the same
-// (one byte per frame) and the line simply is not kept in L2.
-__device__ __forceinline__ void store_flag(unsigned char *flags, unsigned int f, unsigned char v) {
-  __hip_atomic_store(&flags[f], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+// The one result byte of a frame.  `sys` (ScanK::sys_flags, set by the host when `flags` is not device memory — the
+// pipe's zero-copy staging, a caller's hipHostMalloc'ed buffer): a SYSTEM-scope store (global_store_byte ... sc0 sc1:
+// write-through past the XCD's L2, byte-masked) — the kernel then writes pinned host memory over PCIe next to bytes
+// that other workgroups, on other XCDs, write into the same line at other times, so no cache on the way may hold the
+// line and merge it back later.  Device memory takes the plain store: a write-through store is only acknowledged from
+// the memory side, and a workgroup cannot retire before that — measured against round 4's library in one process,
+// system-scope stores for EVERY frame cost 1.2 % on 1080p (16 384 flags per launch) and 4 % on 480p (262 144).
+__device__ __forceinline__ void store_flag(unsigned char *flags, unsigned int f, unsigned char v, int sys) {
+  if (sys) __hip_atomic_store(&flags[f], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  else flags[f] = v;
 }
 
 // Where a spilling workgroup (SPILL) keeps the votes later bands need: the frame's queue, one dword per record of the
@@ -475,7 +478,7 @@ __device__ __forceinline__ void scan_item(
   r0 = r0 < r1 ? r0 : r1;
   const bool sd = has_sd ? (has_sd[f] != 0) : (r1 > r0);
   if (!sd) {                                   // :219-221 — no side data: false
-    if (slice == 0 && tid == 0) store_flag(flags, f, 0);
+    if (slice == 0 && tid == 0) store_flag(flags, f, 0, k.sys_flags);
     ns.have = false;                           // (never set for such a frame today: a step is only pre-issued for frames with side data)
     return;
   }
@@ -863,7 +866,7 @@ __device__ __forceinline__ void scan_item(
   if (local) atomicAdd(total, local);
   __syncthreads();
 
-  if (tid == 0) store_flag(flags, f, (*total >= k.clust_need) ? 1 : 0);
+  if (tid == 0) store_flag(flags, f, (*total >= k.clust_need) ? 1 : 0, k.sys_flags);
   PT_FLUSH();
 }
 

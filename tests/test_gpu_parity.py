@@ -1447,3 +1447,83 @@ def test_recorded_wrong_flag_configuration_through_every_path(gpu_scanner_factor
         out = pipe.drain()
         pipe.close()
         assert [fl for _, fl, _ in out] == want.tolist(), ("pipe", rep)
+
+
+def _raster_frame(rows, gw, mult, special=(), drop=(), lead=0, shift=2, step_px=3):
+    """Records in raster order over grid rows `rows`, `mult` records per cell (all above the threshold), plus extra
+    records for the cells in `special` ((gx, gy) -> extra votes, appended right behind the cell's own), minus the
+    cells in `drop`; `lead` non-voting records in front (shifts every wave instruction against the rows)."""
+    recs = [(1, 1, 0)] * lead
+    for gy in rows:
+        for gx in range(gw):
+            if (gx, gy) in drop:
+                continue
+            n = mult + dict(special).get((gx, gy), 0)
+            recs += [((gx << shift) + 1, (gy << shift) + 1, step_px)] * n
+    a = np.array(recs, dtype=np.int64).reshape(-1, 3)
+    mv = np.zeros(len(a), dtype=m.MV_DTYPE)
+    mv["dst_x"], mv["dst_y"] = a[:, 0], a[:, 1]
+    mv["src_x"], mv["src_y"] = a[:, 0] - a[:, 2], a[:, 1]
+    return mv
+
+
+def test_dense_raster_votes_travel_as_spans_and_count_exactly(gpu_scanner_factory):
+    """Round 5: on banded plans a wave instruction whose queued votes fall into consecutive cells of a row is ONE
+    8-byte span entry (scan_kernels.hip, SpillQ), replayed a counter word at a time.  960x540 / VECTORS_NEEDED 4 /
+    2 bands: whole rows on both sides of the band seam (rows 262..279; band 1 starts at 270) vote with 3 records per
+    cell — one short of active — in raster order; two horizontally adjacent cells get a 4th record, which makes
+    exactly two active neighbours = the 2 clusters the frame needs.  One vote too many or too few anywhere in the
+    replay flips the flag: frames WITHOUT the pair must say no (3 votes everywhere), frames WITH it yes, wherever the
+    pair sits (word boundaries of the 4-bit fields, row ends, the seam rows), however the wave instructions are
+    shifted against the rows (0..70 leading records, 1..5 records per cell), with holes that cut spans short."""
+    import torch
+    p, s = _fine_shipped_env_scanner(gpu_scanner_factory)
+    gw = 960
+    rows = list(range(262, 280))
+    frames, expect = [], []
+    spots = [(5, 275), (7, 275), (8, 275), (15, 275), (16, 275), (63, 276), (64, 276), (957, 277), (956, 277), (2, 278),
+             (1, 278), (400, 269), (401, 270), (402, 271), (333, 268), (500, 262), (501, 279)]
+    for i, (gx, gy) in enumerate(spots):
+        lead = [0, 1, 2, 3, 5, 13, 17, 31, 63, 64, 65, 70][i % 12]
+        pair = (((gx, gy), 1), ((gx + 1, gy), 1)) if gx + 1 < gw else (((gx - 1, gy), 1), ((gx, gy), 1))
+        holes = {(int(x), int(y)) for x, y in zip(np.random.RandomState(i).randint(0, gw, 40), np.random.RandomState(i + 99).choice(rows, 40))}
+        holes -= {c for c, _ in pair}
+        frames.append(_raster_frame(rows, gw, 3, special=pair, drop=holes if i % 3 == 0 else (), lead=lead))
+        expect.append(1)
+        frames.append(_raster_frame(rows, gw, 3, drop=holes if i % 3 == 0 else (), lead=lead))          # no pair: 3 votes everywhere
+        expect.append(0)
+    for mult, lead in ((1, 7), (2, 9), (4, 3), (5, 11)):                   # every cell 1 / 2 records: no; 4 / 5 records: every cell active
+        frames.append(_raster_frame(rows, gw, mult, lead=lead))
+        expect.append(1 if mult >= 4 else 0)
+    b = m.FrameBatch.from_frames(frames)
+    want = assert_scan_parity(s, p, b.mv, b.frame_off, b.has_sd)
+    assert want.tolist() == expect
+    rec8 = torch.from_numpy(m.pack_records(b.mv).view(np.uint8).copy()).cuda()
+    got8 = s.check_frames_device_compact(rec8, torch.from_numpy(b.frame_off.astype(np.int64)).cuda(), None)
+    assert got8.cpu().numpy().tolist() == expect
+
+
+@pytest.mark.parametrize("vec,force_fb", [(3, None), (6, None), (8, None), (12, None), (4, 32)])
+def test_spans_on_other_banded_counter_forms(gpu_scanner_factory, vec, force_fb):
+    """The same dense raster input on the other forms a banded plan can take: 4-bit fields at VECTORS_NEEDED 3, 8-bit
+    thermometer fields (runs are cut every 4 lanes there: equal cells follow each other, no spans), 8-bit CAS fields
+    (VECTORS_NEEDED 12) and forced 32-bit counters (many narrow bands) — the span replay's generic cell-by-cell path."""
+    kw = dict(m.config.SHIPPED_ENV)
+    kw.update(block_size=4, block_shift=2, vectors_needed=vec)
+    p = ob.params_from_config(3840, 2160, **kw)
+    s = gpu_scanner_factory(p, force_fb=force_fb)
+    assert s.plan["bands"] >= 2
+    band_rows = s.plan["band_rows"]
+    seam = p.vertical_margin + band_rows                      # first centre row of band 1
+    rows = list(range(seam - 4, seam + 5))
+    frames, expect = [], []
+    for i, gx in enumerate((3, 8, 62, 500, 957)):
+        gy = rows[(2 * i) % len(rows)]
+        pair = (((gx, gy), 1), ((gx + 1, gy), 1))
+        frames.append(_raster_frame(rows, 960, vec - 1, special=pair, lead=5 * i + 1))
+        expect.append(1)
+        frames.append(_raster_frame(rows, 960, vec - 1, lead=5 * i + 1))
+        expect.append(0)
+    b = m.FrameBatch.from_frames(frames)
+    want = assert_scan_parity(s, p, b.mv, b.frame_off, b.has_sd)
+    assert want.tolist() == expect
