@@ -295,16 +295,18 @@ __device__ __forceinline__ void store_flag(unsigned char *flags, unsigned int f,
 // Where a spilling workgroup (SPILL) keeps the votes later bands need: the frame's queue, one dword per record of the
 // frame, filled from both ends —
 //   singles  from the BACK, one dword per vote (or run of same-cell votes): (run - 1) << 30 | gy << 15 | gx
-//   spans    from the FRONT, two dwords for a whole wave instruction whose queued votes fall into CONSECUTIVE cells of
-//            one grid row, all with the same run length except possibly the first and the last cell (a block's
-//            records cut by the edge of the wave instruction) — what raster-ordered records produce wherever motion
-//            is dense:  {(run - 1) << 30 | gy << 15 | gx of the first cell,
-//                        cells | (first run - 1) << 8 | (last run - 1) << 10}
+//   spans    from the FRONT, two dwords for three or more queued votes of one wave instruction that fall into
+//            CONSECUTIVE cells of one grid row with equal run lengths — what raster-ordered records produce wherever
+//            motion is dense:  {(run - 1) << 30 | gy << 15 | gx of the first cell, number of cells}.  A wave
+//            instruction is cut into such segments wherever the cells stop being consecutive (end of a grid row, a
+//            block that did not move) or the run length changes (a block's records cut by the edge of the
+//            instruction); segments of one or two votes go to the singles.
 // Round 5 measured what vote-heavy input costs on banded plans (profiles/r05_ab_spill_3_ablations.log): not the votes
 // (LDS votes removed: no change), not the replay (3 %), but the queue's STORES — 1-5 % of extra write traffic into a
 // saturated read stream cost 8-11 % of its rate, whatever their cache policy, order or instruction form.  A span entry
-// is 8 bytes where the same votes took up to 256: the queue of a frame in which every record votes shrinks 32-fold
-// (one record per cell) or 8-fold (four per cell).  A span covers >= 3 votes, so the two ends never meet.
+// is 8 bytes where the same votes took up to 256: the queue of a frame in which every record votes shrinks about
+// 30-fold (one record per cell) or 4- to 8-fold (four per cell).  A span stands for >= 3 votes in 2 dwords, a single
+// for one vote in one: the two ends never meet.
 struct SpillQ {
   unsigned int *q;        // this frame's queue: n dwords
   unsigned int n;         // its size in dwords (records of the frame, at most 2^32 - 1)
@@ -315,24 +317,29 @@ struct SpillQ {
 // `r` votes for each of the cells [c0, c0 + n) of the tile (consecutive cells of one row: a replayed span).  Thermometer
 // fields: a counter WORD at a time — one look, the next clear bits of every field of the word in ONE returning OR
 // (8 cells of a 4-bit form), and only the votes that lost a race to another wave settle cell by cell; other forms
-// cell by cell.
+// cell by cell.  `rot`: the word the walk starts at (it wraps around) — the lanes of a wave replay consecutive spans,
+// whose words lie a fixed stride apart: started at the same relative word they would all hit a handful of LDS banks.
 template <int FB, int MODE>
-__device__ __forceinline__ void bump_cells(unsigned int *cnt, unsigned int c0, unsigned int n, unsigned int r, unsigned int cap) {
+__device__ __forceinline__ void bump_cells(unsigned int *cnt, unsigned int c0, unsigned int n, unsigned int r, unsigned int cap,
+                                           unsigned int rot) {
   if constexpr (MODE == MODE_UNARY && FB >= 2 && FB <= 8) {
     constexpr unsigned int CPW = 32u / FB, FM = (1u << FB) - 1u;
+    if (n == 0u) return;
     const unsigned int rr = r < cap ? r : cap;
-    unsigned int c = c0;
-    const unsigned int end = c0 + n;
-    while (c < end) {
-      const unsigned int wi = c / CPW, lo = c - wi * CPW, hi = min(CPW, end - wi * CPW);
+    constexpr unsigned int EVERY = 0xffffffffu / FM;                     // bit 0 of every field: 0x11111111 for 4-bit fields
+    const unsigned int low_rr = EVERY * ((1u << rr) - 1u), cap_ones = EVERY * ((1u << cap) - 1u);
+    const unsigned int end = c0 + n, first_w = c0 / CPW, last_w = (end - 1u) / CPW, nw = last_w - first_w + 1u;
+    unsigned int at = rot % nw;
+    for (unsigned int i = 0; i < nw; ++i) {
+      const unsigned int wi = first_w + at;
+      at = at + 1u == nw ? 0u : at + 1u;
+      const unsigned int lo = wi == first_w ? c0 - first_w * CPW : 0u, hi = wi == last_w ? end - last_w * CPW : CPW;
       const unsigned int x = cnt[wi];
-      unsigned int m = 0u;
-#pragma unroll
-      for (unsigned int q = 0; q < CPW; ++q) {
-        const unsigned int j = (unsigned int)__popc((x >> (q * FB)) & FM);
-        const unsigned int take = (q >= lo && q < hi && j < cap) ? min(rr, cap - j) : 0u;
-        m |= (((1u << take) - 1u) << j) << (q * FB);
-      }
+      // every field of the word at once: a thermometer code grows by rr when it is shifted up by rr and its low rr
+      // bits are set — what the shift pushes out of a field's top lands in the low rr bits of the next field, which
+      // are set anyway — and stays within `cap` ones under the cap pattern; `sel` keeps the fields [lo, hi)
+      const unsigned int sel = (hi == CPW ? 0xffffffffu : (1u << (hi * FB)) - 1u) & ~((1u << (lo * FB)) - 1u);
+      const unsigned int m = (((x << rr) | low_rr) & cap_ones & sel) & ~x;
       if (m != 0u) {
         const unsigned int lost = m & atomicOr(&cnt[wi], m);       // bits somebody else set between look and OR
         if (lost != 0u) {
@@ -343,7 +350,6 @@ __device__ __forceinline__ void bump_cells(unsigned int *cnt, unsigned int c0, u
           }
         }
       }
-      c = wi * CPW + hi;
     }
   } else {
     for (unsigned int c = 0; c < n; ++c) bump_n<FB, MODE>(cnt, c0 + c, r, cap);
@@ -400,35 +406,39 @@ __device__ __forceinline__ void vote(const MvFields m, const ScanK &k, int t0, i
       const unsigned long long qm = __ballot(qv);
       if (qm != 0ull) {
         const int leader = __ffsll((long long)qm) - 1;
-        const unsigned int nq = (unsigned int)__popcll(qm);
         const unsigned int rank = (unsigned int)__popcll(qm & ((1ull << lane) - 1ull));   // queued votes below this lane
         const unsigned int r4 = min(run, 4u) - 1u;
         const unsigned int e = (r4 << 30) | key;
-        // a span: the queued votes of this wave instruction are cells c, c + 1, c + 2, ... of one row (the keys then
-        // differ by exactly 1 from vote to vote: gy << 15 | gx with gx < 32768) and their runs are equally long
-        bool span = false;
-        unsigned int hdr0 = 0u, hdr1 = 0u;
-        if (nq >= 3u) {                                           // (wave-uniform)
-          const unsigned long long rest = qm & (qm - 1ull);       // without the first queued lane
-          const int second = __ffsll((long long)rest) - 1, last = 63 - __clzll((long long)qm);
-          const unsigned int key0 = (unsigned int)__builtin_amdgcn_readlane((int)key, leader);
-          const unsigned int rf = (unsigned int)__builtin_amdgcn_readlane((int)r4, leader);
-          const unsigned int rm = (unsigned int)__builtin_amdgcn_readlane((int)r4, second);
-          const unsigned int rl = (unsigned int)__builtin_amdgcn_readlane((int)r4, last);
-          span = __ballot(qv && ((key - rank != key0) || (lane != leader && lane != last && r4 != rm))) == 0ull;
-          hdr0 = (rm << 30) | key0;
-          hdr1 = nq | (rf << 8) | (rl << 10);
+        // segments: maximal stretches of queued votes whose entries count up by exactly one from vote to vote —
+        // consecutive cells (gy << 15 | gx, gx < 32768: the next cell of the SAME row) with the same run length
+        const unsigned long long below = (1ull << lane) - 1ull;
+        const unsigned int d = e - rank;
+        const unsigned long long qb = qm & below;
+        const int prev_lane = qb ? 63 - __clzll((long long)qb) : lane;              // the queued lane below this one
+        const unsigned int d_prev = (unsigned int)__shfl((int)d, prev_lane);
+        const unsigned long long sh = __ballot(qv && (qb == 0ull || d != d_prev));   // first vote of every segment
+        const unsigned long long at_or_below = sh & (below | (1ull << lane));
+        const int seg_lo = at_or_below ? 63 - __clzll((long long)at_or_below) : 0;
+        const unsigned long long heads_above = (lane < 63) ? (sh >> (lane + 1)) << (lane + 1) : 0ull;
+        const int seg_hi = heads_above ? __ffsll((long long)heads_above) - 1 : 64;   // [seg_lo, seg_hi): this lane's segment
+        const unsigned long long seg_mask = (seg_hi >= 64 ? ~0ull : ((1ull << seg_hi) - 1ull)) & ~((1ull << seg_lo) - 1ull);
+        const unsigned int seg_len = (unsigned int)__popcll(qm & seg_mask);
+        const bool span_head = qv && lane == seg_lo && seg_len >= 3u;
+        const bool single = qv && seg_len < 3u;
+        const unsigned long long spans = __ballot(span_head), singles = __ballot(single);
+        unsigned int base_s = 0u, base_1 = 0u;
+        if (lane == leader) {
+          if (spans != 0ull) base_s = atomicAdd(sq.tail + 1, 2u * (unsigned int)__popcll(spans));
+          if (singles != 0ull) base_1 = atomicAdd(sq.tail, (unsigned int)__popcll(singles));
         }
-        unsigned int base = 0u;
-        if (lane == leader) base = atomicAdd(span ? sq.tail + 1 : sq.tail, span ? 2u : nq);
-        base = (unsigned int)__builtin_amdgcn_readlane((int)base, leader);
-        if (span) {
-          if (lane == leader) {
-            sq.q[base] = hdr0;
-            sq.q[base + 1u] = hdr1;
-          }
-        } else if (qv) {
-          sq.q[sq.n - 1u - (base + rank)] = e;
+        base_s = (unsigned int)__builtin_amdgcn_readlane((int)base_s, leader);
+        base_1 = (unsigned int)__builtin_amdgcn_readlane((int)base_1, leader);
+        if (span_head) {
+          const unsigned int at = base_s + 2u * (unsigned int)__popcll(spans & below);
+          sq.q[at] = e;
+          sq.q[at + 1u] = seg_len;
+        } else if (single) {
+          sq.q[sq.n - 1u - (base_1 + (unsigned int)__popcll(singles & below))] = e;
         }
       }
     }
@@ -709,10 +719,8 @@ __device__ __forceinline__ void scan_item(
         const unsigned int n0 = more ? sq.q[2u * nx] : 0u, n1 = more ? sq.q[2u * nx + 1u] : 0u;
         const int gy = (int)((h0 >> 15) & 0x7fffu), gx = (int)(h0 & 0x7fffu);
         if (gy >= t0 && gy < t1) {
-          const unsigned int cell0 = (unsigned int)((gy - t0) * k.gw + gx), len = h1 & 0xffu;      // len >= 3
-          bump_n<FB, MODE>(cnt, cell0, ((h1 >> 8) & 3u) + 1u, k.vec_need);                          // first cell: its own run
-          bump_cells<FB, MODE>(cnt, cell0 + 1u, len - 2u, (h0 >> 30) + 1u, k.vec_need);
-          bump_n<FB, MODE>(cnt, cell0 + len - 1u, ((h1 >> 10) & 3u) + 1u, k.vec_need);              // last cell: its own run
+          bump_cells<FB, MODE>(cnt, (unsigned int)((gy - t0) * k.gw + gx), h1, (h0 >> 30) + 1u, k.vec_need,
+                               ((unsigned int)tid >> 2) & 7u);
         }
         h0 = n0; h1 = n1; sp = nx; have = more;
       }
