@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out
 COMMON="--cpu-seconds 0 --no-others --no-host"
 run() { name=$1; shift; echo "== $name $(date +%T)"; "$@" > $O/$name.log 2>&1 || { tail -5 $O/$name.log; exit 1; }; }
-rm -f $O/r05_pmc_traffic.json
+[ -n "$KEEP_PMC" ] || rm -f $O/r05_pmc_traffic.json
 leg() {   # tag workload params frames steps key
   tag=$1; wl=$2; pn=$3; fr=$4; st=$5; key=$6
   A="--workload $wl --params $pn --frames $fr $COMMON"
