@@ -741,19 +741,31 @@ def _run_rank(a):
     lib = m.load_library()
     st = torch.cuda.current_stream(dev).cuda_stream
     nbytes = (d_mv.numel() // 16) * 16
-    frame_bytes = 40 * max(1, n_records // max(1, a.frames - a.frames // 30))     # a P-frame of this workload
+    frame_bytes = 40 * int(spec.records_per_frame)                                # a P-frame of this workload (ragged workloads: its nominal size)
     sweep = {}
-    for shape, sname in ((1, "12of40"), (0, "16B")):
-        for chunk in (frame_bytes, 1280 * 1024, 5 * 1024 * 1024):
-            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for shape, sname, chunks, idle in ((2, "12of40+arith", (frame_bytes, 1280 * 1024), 30), (2, "12of40+arith", (frame_bytes, 1280 * 1024), 0),
+                                       (3, "12of40+arith+lds", (frame_bytes,), 30), (1, "12of40", (1280 * 1024, 5 * 1024 * 1024), 0),
+                                       (0, "16B", (1280 * 1024, 5 * 1024 * 1024), 0)):
+        for chunk in chunks:
             for _ in range(3):
-                m._abi.check(lib.mtgpu_debug_read_ceiling_shape(scanner._ctx, d_mv.data_ptr(), nbytes, shape, chunk, st))
-            c0.record()
-            for _ in range(20):
-                m._abi.check(lib.mtgpu_debug_read_ceiling_shape(scanner._ctx, d_mv.data_ptr(), nbytes, shape, chunk, st))
-            c1.record()
+                m._abi.check(lib.mtgpu_debug_read_ceiling_shape(scanner._ctx, d_mv.data_ptr(), nbytes, shape, chunk, idle, st))
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+            for c0, c1 in evs:           # an event pair around every launch, exactly as the scan kernel is timed
+                c0.record()
+                m._abi.check(lib.mtgpu_debug_read_ceiling_shape(scanner._ctx, d_mv.data_ptr(), nbytes, shape, chunk, idle, st))
+                c1.record()
             torch.cuda.synchronize()
-            sweep[f"{sname}/{chunk}"] = nbytes / (c0.elapsed_time(c1) / 20 * 1e-3) / 1e9
+            sweep[f"{sname}/{chunk}" + (f"/idle{idle}" if idle else "")] = \
+                nbytes / (float(np.mean([c0.elapsed_time(c1) for c0, c1 in evs])) * 1e-3) / 1e9
+    # ... and the scan itself once more, timed the same way in the same phase of the run (clocks and the memory
+    # system's state drift over a run: the timed loop ran seconds earlier)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+    for c0, c1 in evs:
+        c0.record()
+        scanner.check_frames_device(d_mv, d_off, None, flag_bufs[0])
+        c1.record()
+    torch.cuda.synchronize()
+    scan_in_sweep = alg_bytes / (float(np.mean([c0.elapsed_time(c1) for c0, c1 in evs])) * 1e-3) / 1e9
     read_ceiling_best = max(sweep, key=sweep.get)
     read_ceiling = sweep[read_ceiling_best]
     flags_host = d_flags.cpu().numpy()
@@ -817,9 +829,10 @@ def _run_rank(a):
         roof = roofline_of(alg_bytes, kern_ms)
         roof.update({"traffic": traffic, "traffic_source": traffic_source, "measured_read_ceiling": read_ceiling,
                      "measured_read_ceiling_is": f"best of a sweep of read-only kernels on the same buffer: {read_ceiling_best} "
-                                                 "(load shape / bytes per workgroup)",
+                                                 "(load shape / bytes per workgroup [/ every n-th workgroup idle])",
                      "read_ceiling_sweep_GBps": {k_: round(v_, 1) for k_, v_ in sweep.items()},
-                     "frac_of_measured_ceiling": roof["achieved"] / read_ceiling})
+                     "scan_rate_next_to_the_sweep_GBps": scan_in_sweep,
+                     "frac_of_measured_ceiling": scan_in_sweep / read_ceiling})
         line = {
             "metric": "MV-scan frames/sec at 1080p grid" if a.workload.startswith("1080p") else "MV-scan frames/sec",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,

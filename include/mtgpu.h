@@ -150,12 +150,14 @@ int mtgpu_plan_preview(const mt_scan_params *params, int lds_bytes_per_workgroup
 int mtgpu_set_slices(mtgpu_ctx *ctx, int slices);
 
 /* Calibration only (bench.py): stream `bytes` of a device buffer and discard them — what a kernel that ONLY reads
- * reaches on that buffer.  shape 0: 16 contiguous bytes per lane; shape 1: the scan's own access (bytes 4..15 of
- * every 40-byte record); chunk_bytes: contiguous bytes per 512-thread workgroup (0 = 1.25 MiB; one frame's bytes
- * makes shape 1 the scan kernel minus its votes).  bench.py reports the best of a small sweep as the measured
- * ceiling.  Asynchronous on `stream`.  mtgpu_debug_read_ceiling = shape 0, default chunk. */
+ * reaches on that buffer.  shape 0: 16 contiguous bytes per lane; 1: the scan's own access (bytes 4..15 of every
+ * 40-byte record); 2: shape 1 plus the scan's arithmetic on a record that does not vote; 3: shape 2 inside the scan's
+ * LDS phases (tile zeroed first, walked once at the end).  chunk_bytes: contiguous bytes per 512-thread workgroup
+ * (0 = 1.25 MiB; one frame's bytes makes shapes 1-3 the scan kernel with the votes taken out).  idle_every > 1: every
+ * idle_every-th workgroup has nothing to do, as the frames without records of a stream.  bench.py reports the best
+ * of a small sweep as the measured ceiling.  Asynchronous on `stream`.  mtgpu_debug_read_ceiling = shape 0, defaults. */
 int mtgpu_debug_read_ceiling_shape(mtgpu_ctx *ctx, const void *d_buf, uint64_t bytes, int shape, uint64_t chunk_bytes,
-                                   void *stream);
+                                   uint32_t idle_every, void *stream);
 int mtgpu_debug_read_ceiling(mtgpu_ctx *ctx, const void *d_buf, uint64_t bytes, void *stream);
 
 /*

@@ -711,22 +711,22 @@ int mtgpu_pack_records_with(int impl_flags, const void *mv_bytes, uint64_t n_rec
 int mtgpu_pack_selected(void) { return mtgpu::pack_selected(); }
 
 int mtgpu_debug_read_ceiling_shape(mtgpu_ctx *c, const void *d_buf, uint64_t bytes, int shape, uint64_t chunk_bytes,
-                                   void *stream) {
+                                   uint32_t idle_every, void *stream) {
   if (!c) return fail(MT_ERR_INVALID, "ctx is NULL");
   if (!d_buf || ((uintptr_t)d_buf & 15u)) return fail(MT_ERR_INVALID, "buffer must be non-NULL and 16-byte aligned");
-  if (shape != 0 && shape != 1) return fail(MT_ERR_INVALID, "shape must be 0 (16-byte contiguous) or 1 (12 of 40 bytes)");
+  if (shape < 0 || shape > 3) return fail(MT_ERR_INVALID, "shape must be 0 (16-byte contiguous), 1 (12 of 40 bytes), 2 (1 + the scan's per-record arithmetic) or 3 (2 + the scan's LDS phases)");
   HIP_TRY(hipSetDevice(c->device));
   std::lock_guard<std::mutex> lock(c->mu);
   int rc = c->d_sd.reserve(64);                      // 4-byte sink lives in a staging buffer
   if (rc != MT_OK) return rc;
-  hipError_t e = mtgpu::launch_read_ceiling(d_buf, bytes, shape, chunk_bytes, static_cast<unsigned int *>(c->d_sd.p),
-                                            static_cast<hipStream_t>(stream));
+  hipError_t e = mtgpu::launch_read_ceiling(d_buf, bytes, shape, chunk_bytes, (unsigned int)c->plan.lds_bytes, idle_every,
+                                            static_cast<unsigned int *>(c->d_sd.p), static_cast<hipStream_t>(stream));
   if (e != hipSuccess) return hip_fail(e, "read ceiling launch");
   return MT_OK;
 }
 
 int mtgpu_debug_read_ceiling(mtgpu_ctx *c, const void *d_buf, uint64_t bytes, void *stream) {
-  return mtgpu_debug_read_ceiling_shape(c, d_buf, bytes, 0, 0, stream);
+  return mtgpu_debug_read_ceiling_shape(c, d_buf, bytes, 0, 0, 0, stream);
 }
 
 int mtgpu_set_slices(mtgpu_ctx *c, int slices) {

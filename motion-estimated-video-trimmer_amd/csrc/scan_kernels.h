@@ -59,6 +59,6 @@ hipError_t launch_check_offsets(const unsigned long long *frame_off, unsigned in
                                 hipStream_t stream);
 // calibration: shape 0 = 16 contiguous bytes per lane, 1 = the scan's 12-of-40-byte records; chunk = bytes per workgroup (0: 1.25 MiB)
 hipError_t launch_read_ceiling(const void *p, unsigned long long bytes, int shape, unsigned long long chunk,
-                               unsigned int *sink, hipStream_t stream);
+                               unsigned int lds_bytes, unsigned int skip, unsigned int *sink, hipStream_t stream);
 
 }  // namespace mtgpu

@@ -48,6 +48,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
 #include <atomic>
 
 #include "knobs.h"
@@ -911,13 +912,31 @@ __global__ __launch_bounds__(BLOCK) void scan_frames_kernel(
 // and reports the best:
 //   SHAPE 0  16 contiguous bytes per lane (every byte of the buffer crosses into the CU)
 //   SHAPE 1  the scan's own: bytes 4..15 of every 40-byte record, one record per lane (every LINE is fetched, 12 of
-//            40 bytes reach the registers) — with a chunk of one frame this is the scan kernel minus its votes
+//            40 bytes reach the registers)
+//   SHAPE 2  SHAPE 1 plus the arithmetic the scan spends on a record that does not vote (decode, |d|^2, compare, one
+//            ballot per wave instruction)
+//   SHAPE 3  SHAPE 2 inside the scan's frame: the workgroup first zeroes an LDS tile of the plan's size and walks it
+//            once at the end — with a chunk of one frame this is the scan kernel with the votes taken out
 template <int SHAPE>
 __global__ __launch_bounds__(512) void read_ceiling_kernel(const unsigned char *__restrict__ p, unsigned long long bytes,
-                                                           unsigned long long chunk, unsigned int *__restrict__ sink) {
-  const unsigned long long c0 = (unsigned long long)blockIdx.x * chunk;
+                                                           unsigned long long chunk, unsigned long long thr,
+                                                           unsigned int lds_words, unsigned int skip,
+                                                           unsigned int *__restrict__ sink) {
+  // `skip` > 1: every skip-th workgroup has nothing to do and leaves at once — the I-frames of a stream (frames
+  // without records), which stagger the workgroups of a launch against each other
+  unsigned long long cb = blockIdx.x;
+  if (skip > 1u) {
+    if (blockIdx.x % skip == 0u) return;
+    cb = blockIdx.x - (blockIdx.x / skip + 1u);
+  }
+  const unsigned long long c0 = min(bytes, cb * chunk);
   const unsigned long long c1 = min(bytes, c0 + chunk);
-  constexpr unsigned long long UNIT = SHAPE == 0 ? 16ull : 40ull;
+  constexpr unsigned long long UNIT = SHAPE == 0 ? 16ull : 40ull;      // (SHAPE 2 = SHAPE 1 plus the scan's per-record arithmetic)
+  extern __shared__ __attribute__((aligned(16))) unsigned int tile[];
+  if constexpr (SHAPE == 3) {                                           // the scan's phase 0: zero the workgroup's LDS tile
+    for (unsigned int q = threadIdx.x; q < lds_words / 4u; q += 512u) reinterpret_cast<u32x4 *>(tile)[q] = (u32x4){0u, 0u, 0u, 0u};
+    __syncthreads();
+  }
   const unsigned char *base = p + c0;
   const unsigned long long n = (c1 - c0) / UNIT;
   unsigned long long i = threadIdx.x;
@@ -934,35 +953,70 @@ __global__ __launch_bounds__(512) void read_ceiling_kernel(const unsigned char *
 #pragma unroll
       for (int u = 0; u < 4; ++u) v[u] = load_fields<0>(base + (i + (unsigned long long)u * 512ull) * 40ull);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) acc ^= v[u].x ^ v[u].y ^ v[u].z;
+      for (int u = 0; u < 4; ++u) {
+        if constexpr (SHAPE >= 2) {
+          // ... and what the scan does with a record that does not vote: decode, |d|^2, compare, one ballot
+          const MvFields m = decode(v[u]);
+          const unsigned int dx = (unsigned int)(m.dst_x - m.src_x), dy = (unsigned int)(m.dst_y - m.src_y);
+          const unsigned long long mag = (unsigned long long)(dx * dx) + (unsigned long long)(dy * dy);
+          acc += (unsigned int)__popcll(__ballot(mag >= thr));       // thr: a kernel argument no record reaches
+        } else {
+          acc ^= v[u].x ^ v[u].y ^ v[u].z;
+        }
+      }
     }
   }
-  for (; i < n; i += 512ull) {
-    if constexpr (SHAPE == 0) {
-      const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_a16 *>(base + i * 16ull));
-      acc ^= v.x ^ v.y ^ v.z ^ v.w;
-    } else {
-      const u32x3 v = load_fields<0>(base + i * 40ull);
-      acc ^= v.x ^ v.y ^ v.z;
+  {
+    // the rest (fewer than one step): every load issued before the first one is used, as in the scan's tail — one
+    // memory round trip, not up to four in a row at the end of every workgroup's life
+    bool ok[4];
+    u32x4 v0[4];
+    u32x3 v1[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const unsigned long long q = i + (unsigned long long)u * 512ull;
+      ok[u] = q < n;
+      v0[u] = (u32x4){0u, 0u, 0u, 0u};
+      v1[u] = (u32x3){0u, 0u, 0u};
+      if (ok[u]) {
+        if constexpr (SHAPE == 0) v0[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_a16 *>(base + q * 16ull));
+        else v1[u] = load_fields<0>(base + q * 40ull);
+      }
     }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (ok[u]) acc ^= v0[u].x ^ v0[u].y ^ v0[u].z ^ v0[u].w ^ v1[u].x ^ v1[u].y ^ v1[u].z;
+  }
+  if constexpr (SHAPE == 3) {                                           // the scan's phase 2, in outline: one pass over the tile
+    __syncthreads();
+    for (unsigned int q = threadIdx.x; q < lds_words; q += 512u) acc += tile[q];
   }
   if (acc == 0x9E3779B9u) *sink = acc;   // keeps the loads alive
 }
 
 hipError_t launch_read_ceiling(const void *p, unsigned long long bytes, int shape, unsigned long long chunk,
-                               unsigned int *sink, hipStream_t stream) {
+                               unsigned int lds_bytes, unsigned int skip, unsigned int *sink, hipStream_t stream) {
   if (chunk == 0) chunk = 1280ull * 1024ull;
   if (shape == 0) chunk &= ~15ull;           // chunks of whole 16-byte units (the buffer itself is 16-byte aligned)
   else chunk -= chunk % 40ull;               // ... of whole records
   if (chunk == 0 || bytes < chunk) return hipSuccess;
-  const unsigned long long blocks = (bytes + chunk - 1) / chunk;
+  unsigned long long blocks = (bytes + chunk - 1) / chunk;
+  if (skip > 1u) blocks = blocks + blocks / (skip - 1u) + 2u;     // room for the workgroups that leave at once
   if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
   if (shape == 0)
     hipLaunchKernelGGL(read_ceiling_kernel<0>, dim3((unsigned int)blocks), dim3(512), 0, stream,
-                       static_cast<const unsigned char *>(p), bytes, chunk, sink);
+                       static_cast<const unsigned char *>(p), bytes, chunk, 1ull << 40, 0u, skip, sink);
+  else if (shape == 3) {
+    // (<= 64 KB of LDS: the default limit of a kernel that never asked for more)
+    const unsigned int lb = std::min(lds_bytes, 64u * 1024u) & ~15u;
+    hipLaunchKernelGGL(read_ceiling_kernel<3>, dim3((unsigned int)blocks), dim3(512), lb, stream,
+                       static_cast<const unsigned char *>(p), bytes, chunk, 1ull << 40, lb / 4u, skip, sink);
+  } else if (shape == 2)
+    hipLaunchKernelGGL(read_ceiling_kernel<2>, dim3((unsigned int)blocks), dim3(512), 0, stream,
+                       static_cast<const unsigned char *>(p), bytes, chunk, 1ull << 40, 0u, skip, sink);
   else
     hipLaunchKernelGGL(read_ceiling_kernel<1>, dim3((unsigned int)blocks), dim3(512), 0, stream,
-                       static_cast<const unsigned char *>(p), bytes, chunk, sink);
+                       static_cast<const unsigned char *>(p), bytes, chunk, 1ull << 40, 0u, skip, sink);
   return hipGetLastError();
 }
 
