@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Round-5 A/B of how banded plans write and replay their spill queue (scan_kernels.hip: DEFER / PIPE / DROP / DEEP),
-all variants interleaved in ONE process on the same resident batch.  Needs the experiments build:
+all variants interleaved in ONE process on the same resident batch.  HISTORICAL: the variants exist only in the
+experiments build of commit 00598d2 (git checkout 00598d2 -- motion-estimated-video-trimmer_amd/csrc); they measured equal
+and were removed again when the span queue went in (c9d1a87).  Logs: profiles/r05_ab_spill_*.log.  Needs that build:
 
     make -C motion-estimated-video-trimmer_amd/csrc experiments
     MTGPU_LIBRARY=$PWD/motion-estimated-video-trimmer_amd/libmtgpu_experiments.so python scripts/ab_spill_r05.py
