@@ -957,3 +957,35 @@ def test_pipe_staging_reuse_stress(gpu_scanner_factory, layout):
     assert len(got) == 6000
     bad = [(i, tag) for i, (_, fl, tag) in enumerate(got) if fl != want_pool[tag]]
     assert not bad, bad[:10]
+
+
+def test_pipe_flag_bytes_own_their_lines(gpu_scanner_factory):
+    """Round 5: the flag bytes — the only part of a staging block the DEVICE writes — start on a 128-byte
+    line of their own and no host-written array (pts, tags) shares a line with them, for every frame capacity that
+    used to put them right behind the tags; results as the oracle says."""
+    import ctypes as C
+    p = ob.params_from_config(1920, 1080, vectors_needed=1)
+    s = gpu_scanner_factory(p)
+    lib = m.load_library()
+    spec = synth.spec_1080p(seed=21, sub=1)
+    spec.events = [synth.Event(1, 9, 40, 30, 4, 3, 9, 2)]
+    mv, off, pts, sd = synth.gen_stream(spec, 12)
+    want = ob.scan_frames(p, mv, off, sd).tolist()
+    for max_frames in (1, 7, 12, 32, 33, 100):
+        for layout in (m._abi.LAYOUT_COMPACT8 | m._abi.LAYOUT_ZERO_COPY, m._abi.LAYOUT_AOS40):
+            pipe = m.ScanPipe(s, 8160 * 12, max_frames, 2, layout=layout)
+            n = min(12, max_frames)
+            for i in range(n):
+                fr = mv[int(off[i]):int(off[i + 1])]
+                pipe.feed(fr if sd[i] else None, float(pts[i]), tag=i)
+            pipe._submit()
+            b, fl, pt, tg, cnt = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint32()
+            m._abi.check(lib.mtgpu_pipe_collect(pipe._pipe, C.byref(b), C.byref(fl), C.byref(pt), C.byref(tg), C.byref(cnt)))
+            assert cnt.value == n and fl.value % 128 == 0
+            assert fl.value - (tg.value + 8 * (max_frames + 1)) >= 0           # behind the whole tag array ...
+            assert (tg.value + 8 * (max_frames + 1) - 1) // 128 < fl.value // 128   # ... and on a later line than its last byte
+            got = np.ctypeslib.as_array(C.cast(fl, C.POINTER(C.c_uint8)), (n,)).tolist()
+            assert got == want[:n], (max_frames, layout)
+            m._abi.check(lib.mtgpu_pipe_release(pipe._pipe, b))
+            pipe._inflight -= 1
+            pipe.close()
