@@ -39,3 +39,50 @@ def test_cpp_host_layer(tmp_path):
     assert all(s[6] == "1" for s in seeks)                          # every landing frame is a keyframe
     if "skipped" not in kv["init_error"]:
         assert "no CPU fallback" in kv["init_error"]
+
+
+def _build_recipe(tmp_path):
+    exe = str(tmp_path / "integration_recipe")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "integration_recipe.cpp"), "-o", exe, "-L" + PKG, "-lmtgpu",
+                           "-Wl,-rpath," + PKG, "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def test_integration_recipe_compiles_against_the_header(tmp_path):
+    """INTEGRATION.md section 1 (the pipe at the check_frame call site), member for member in
+    tests/cpp/integration_recipe.cpp: it must compile and link against include/mtgpu.h as written, and every
+    entry point the text tells a maintainer to call must really appear in it."""
+    _build_recipe(tmp_path)
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    src = open(os.path.join(ROOT, "tests", "cpp", "integration_recipe.cpp")).read()
+    for call in ("mtgpu_pipe_create(", "mtgpu_pipe_acquire(", "mtgpu_batch_add_frame(", "mtgpu_pipe_submit(", "mtgpu_pipe_collect(",
+                 "mtgpu_pipe_release(", "mtgpu_pipe_destroy(", "MT_ERR_CAPACITY", "MT_ERR_BUSY", "in_flight_"):
+        assert call in text and call in src, call
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_integration_recipe_gives_the_oracles_answer(tmp_path):
+    """... and run on the GPU it must find exactly the frames the oracle finds: 90 frames, a 2 x 1-cell object moving
+    in frames 30..59, every 15th frame without side data (45 is one of them) — through 64-record batches, i.e. many
+    rounds of capacity / submit / back-pressure / drain."""
+    import numpy as np
+    import oracle_binding as ob
+    exe = _build_recipe(tmp_path)
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    p = ob.params_from_config(1920, 1080)
+    frames, sd = [], []
+    for f in range(90):
+        mv = np.zeros(4 if 30 <= f < 60 else 0, dtype=m.MV_DTYPE)
+        for k in range(len(mv)):
+            mv["dst_x"][k], mv["dst_y"][k] = 16 * (40 + k // 2) + 8, 16 * 30 + 8
+            mv["src_x"][k], mv["src_y"][k] = mv["dst_x"][k] - 6, mv["dst_y"][k]
+        frames.append(mv)
+        sd.append(f % 15 != 0)
+    want = [f / 30.0 for f in range(90) if sd[f] and ob.check_frame(p, frames[f], True)]
+    assert len(want) == 28                                         # frames 30..59 without 30 and 45
+    assert out.stdout.split() == ["motion", str(len(want)), "first", f"{want[0]:.6f}", "last", f"{want[-1]:.6f}"]
