@@ -743,20 +743,25 @@ def _run_rank(a):
     nbytes = (d_mv.numel() // 16) * 16
     frame_bytes = 40 * int(spec.records_per_frame)                                # a P-frame of this workload (ragged workloads: its nominal size)
     sweep = {}
+    configs = []
     for shape, sname, chunks, idle in ((2, "12of40+arith", (frame_bytes, 1280 * 1024), 30), (2, "12of40+arith", (frame_bytes, 1280 * 1024), 0),
                                        (3, "12of40+arith+lds", (frame_bytes,), 30), (1, "12of40", (1280 * 1024, 5 * 1024 * 1024), 0),
                                        (0, "16B", (1280 * 1024, 5 * 1024 * 1024), 0)):
-        for chunk in chunks:
-            for _ in range(3):
+        configs += [(f"{sname}/{chunk}" + (f"/idle{idle}" if idle else ""), shape, chunk, idle) for chunk in chunks]
+    times = {name: [] for name, _, _, _ in configs}
+    for order in (configs, configs[::-1]):       # two passes in opposite orders: no configuration owes its figure to its place
+        for name, shape, chunk, idle in order:
+            for _ in range(2):
                 m._abi.check(lib.mtgpu_debug_read_ceiling_shape(scanner._ctx, d_mv.data_ptr(), nbytes, shape, chunk, idle, st))
-            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
             for c0, c1 in evs:           # an event pair around every launch, exactly as the scan kernel is timed
                 c0.record()
                 m._abi.check(lib.mtgpu_debug_read_ceiling_shape(scanner._ctx, d_mv.data_ptr(), nbytes, shape, chunk, idle, st))
                 c1.record()
             torch.cuda.synchronize()
-            sweep[f"{sname}/{chunk}" + (f"/idle{idle}" if idle else "")] = \
-                nbytes / (float(np.mean([c0.elapsed_time(c1) for c0, c1 in evs])) * 1e-3) / 1e9
+            times[name] += [c0.elapsed_time(c1) for c0, c1 in evs]
+    for name, t in times.items():
+        sweep[name] = nbytes / (float(np.mean(t)) * 1e-3) / 1e9
     # ... and the scan itself once more, timed the same way in the same phase of the run (clocks and the memory
     # system's state drift over a run: the timed loop ran seconds earlier)
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]

@@ -41,13 +41,21 @@ if which == "bench":
         s.check_frames_device(w["d_mv"], w["d_off"], None, fl)
 else:
     s = m.MotionScanner(m.ScanParams.from_config(1920, 1080), 0)
+    if os.environ.get("PROBE_SECOND_ALLOCATION") == "1":     # bench.py --no-others: the records are the process's SECOND 20 GB block
+        first = torch.empty(15837 * frame, dtype=torch.uint8, device=dev)
+        first.zero_()
     buf = torch.empty(15837 * frame, dtype=torch.uint8, device=dev)
     g = torch.Generator(device=dev)
     g.manual_seed(1)
     tile = torch.randint(0, 256, (60 * frame,), dtype=torch.uint8, device=dev, generator=g)
     buf[: (buf.numel() // tile.numel()) * tile.numel()].view(-1, tile.numel())[:] = tile
+if os.environ.get("PROBE_SECOND_STREAM") == "1":          # what bench.py has and a bare probe has not: a second HIP stream that has run a kernel
+    s2 = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(s2):
+        junk = torch.zeros(1024, device=dev) + 1
+    s2.synchronize()
 nbytes = (buf.numel() // 16) * 16
 print(f"buffer: {which}, {nbytes} bytes at {buf.data_ptr():#x}")
-for order in ((30, 0, 4, 8, 16, 30, 60, 120, 0), (0, 120, 60, 30, 16, 8, 4, 0, 30)):
+for order in ((30, 0, 30, 0), (0, 120, 60, 30, 16, 8, 4, 0, 30)) if os.environ.get("PROBE_SHORT") == "1" else ((30, 0, 4, 8, 16, 30, 60, 120, 0), (0, 120, 60, 30, 16, 8, 4, 0, 30)):
     print(" | ".join(f"idle {i:3d}: {rate(s._ctx, buf, nbytes, i):7.1f}" for i in order), flush=True)
 print("1.25 MiB chunks: " + " | ".join(f"idle {i:3d}: {rate(s._ctx, buf, nbytes, i, 1280 * 1024):7.1f}" for i in (0, 30, 0, 30)), flush=True)
