@@ -924,10 +924,11 @@ __global__ __launch_bounds__(512) void read_ceiling_kernel(const unsigned char *
                                                            unsigned int *__restrict__ sink) {
   // `skip` > 1: every skip-th workgroup has nothing to do and leaves at once — the I-frames of a stream (frames
   // without records), which stagger the workgroups of a launch against each other
-  unsigned long long cb = blockIdx.x;
+  const unsigned int bi = blockIdx.x;
+  unsigned long long cb = bi;
   if (skip > 1u) {
-    if (blockIdx.x % skip == 0u) return;
-    cb = blockIdx.x - (blockIdx.x / skip + 1u);
+    if (bi % skip == 0u) return;
+    cb = bi - (bi / skip + 1u);
   }
   const unsigned long long c0 = min(bytes, cb * chunk);
   const unsigned long long c1 = min(bytes, c0 + chunk);

@@ -58,4 +58,6 @@ nbytes = (buf.numel() // 16) * 16
 print(f"buffer: {which}, {nbytes} bytes at {buf.data_ptr():#x}")
 for order in ((30, 0, 30, 0), (0, 120, 60, 30, 16, 8, 4, 0, 30)) if os.environ.get("PROBE_SHORT") == "1" else ((30, 0, 4, 8, 16, 30, 60, 120, 0), (0, 120, 60, 30, 16, 8, 4, 0, 30)):
     print(" | ".join(f"idle {i:3d}: {rate(s._ctx, buf, nbytes, i):7.1f}" for i in order), flush=True)
+# (two more orders of the workgroups were probed with a kernel that is not kept — XCD-major: every XCD walks one contiguous
+#  eighth of the buffer, 6660 against 6990 GB/s; octets of workgroups rotated by their index: profiles/r05_stagger_probe.txt)
 print("1.25 MiB chunks: " + " | ".join(f"idle {i:3d}: {rate(s._ctx, buf, nbytes, i, 1280 * 1024):7.1f}" for i in (0, 30, 0, 30)), flush=True)
