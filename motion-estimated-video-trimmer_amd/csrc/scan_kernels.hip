@@ -37,10 +37,12 @@
 // Grids whose counters do not fit one LDS tile even packed are cut into ROW BANDS that the
 // SAME workgroup handles one after the other (template SPILL): the records are streamed from
 // HBM exactly once, during band 0; every surviving vote that a later band needs is appended to
-// a per-frame queue in global memory (4 bytes: (run - 1) << 30 | gy << 15 | gx — one entry per RUN of up
-// to 4 same-cell records of a wave instruction; wave-aggregated append, the tail lives in LDS) and bands 1.. replay that queue instead of re-reading 40-byte records.  Typical
-// footage queues almost nothing (only votes above the threshold); the worst case (every record
-// votes, all into later bands) adds 4 B written + 4 B per later band read to each 40-B record.
+// a per-frame queue in global memory (wave-aggregated append, the tails live in LDS) and bands 1.. replay that queue
+// instead of re-reading 40-byte records.  Queue entries (struct SpillQ): 4 bytes for a vote or a run of up to 4 same-cell
+// votes, (run - 1) << 30 | gy << 15 | gx — or 8 bytes for a SPAN, three or more queued votes of one wave instruction in
+// consecutive cells of a row, which is what dense motion in raster-ordered records produces.  Typical
+// footage queues almost nothing (only votes above the threshold); when every record votes, spans keep the queue's
+// write traffic at 0.3-0.6 % of the records read (round 4, one entry per run: 2.4-5 %, which cost 8-11 % of the rate).
 #if !defined(__HIP_DEVICE_COMPILE__) || defined(__gfx950__)
 #else
 #error "scan_kernels.hip is written for gfx950 only (sc1 write-through stores, aux bits, 160 KB LDS)"

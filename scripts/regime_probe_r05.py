@@ -49,7 +49,18 @@ outs = (torch.zeros((S, 64, 2), dtype=torch.float64, device=dev), torch.zeros((S
 probe("2 after the merge inputs / outputs were allocated", scanner, d_mv)
 scanner.check_frames_device(d_mv, d_off, None, d_flags)
 torch.cuda.synchronize()
-probe("3 after one scan launch", scanner, d_mv)
+def scan_rate(tag):
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+    for c0, c1 in evs:
+        c0.record()
+        scanner.check_frames_device(d_mv, d_off, None, d_flags)
+        c1.record()
+    torch.cuda.synchronize()
+    print(f"scan itself [{tag}]: {w['alg_bytes'] / (float(np.mean([c0.elapsed_time(c1) for c0, c1 in evs])) * 1e-3) / 1e9:.0f} GB/s", flush=True)
+
+
+scan_rate("one stream so far")
+probe("3 after 21 scan launches", scanner, d_mv)
 scanner.merge_streams_device(d_flags, d_pts, d_soff, d_mp, True, 64, out=outs)
 torch.cuda.synchronize()
 probe("4 after one merge launch on the same stream", scanner, d_mv)
@@ -67,11 +78,5 @@ for _ in range(5):
     scan_stream.wait_event(back)
 torch.cuda.synchronize()
 probe("5 after five scan + merge steps on two streams with event waits", scanner, d_mv)
-evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
-for c0, c1 in evs:
-    c0.record()
-    scanner.check_frames_device(d_mv, d_off, None, d_flags)
-    c1.record()
-torch.cuda.synchronize()
-print(f"scan itself: {w['alg_bytes'] / (float(np.mean([c0.elapsed_time(c1) for c0, c1 in evs])) * 1e-3) / 1e9:.0f} GB/s", flush=True)
+scan_rate("after the two-stream steps")
 probe("6 after 20 more scans", scanner, d_mv)
