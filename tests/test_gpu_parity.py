@@ -1527,3 +1527,42 @@ def test_spans_on_other_banded_counter_forms(gpu_scanner_factory, vec, force_fb)
     b = m.FrameBatch.from_frames(frames)
     want = assert_scan_parity(s, p, b.mv, b.frame_off, b.has_sd)
     assert want.tolist() == expect
+
+
+def test_device_entry_points_with_flags_in_pinned_host_memory(gpu_scanner_factory):
+    """include/mtgpu.h, "Memory the `*_device` entry points accept": result bytes may live in pinned host memory that
+    the driver allocated (torch's pin_memory = hipHostMalloc); the entry points ask the runtime what `d_flags` is and
+    store at system scope then.  Records resident on the device, flags written over PCIe into a pinned buffer with its
+    own 128-byte lines, read by the host after a stream synchronisation — for single-tile, sliced and banded plans and
+    for both record layouts; a second call into the same pinned buffer overwrites every byte."""
+    import torch
+    spec = synth.spec_1080p(seed=31, sub=2)
+    spec.events = synth.scripted_events(spec, 90)
+    mv, off, pts, sd = synth.gen_stream(spec, 90)
+    cases = [(ob.params_from_config(1920, 1080), None, 0), (ob.params_from_config(1920, 1080, vectors_needed=2), 2, 4)]
+    kw = dict(m.config.SHIPPED_ENV)
+    kw.update(block_size=4, block_shift=2)
+    cases.append((ob.params_from_config(3840, 2160, **kw), None, 0))          # 2 spill bands
+    d_mv = torch.from_numpy(mv.view(np.uint8).reshape(-1).copy()).cuda()
+    d_rec = torch.from_numpy(m.pack_records(mv).view(np.uint8).reshape(-1).copy()).cuda()
+    d_off = torch.from_numpy(off.astype(np.int64)).cuda()
+    d_sd = torch.from_numpy(sd).cuda()
+    seen = []
+    for p, fb, slices in cases:
+        s = gpu_scanner_factory(p, force_fb=fb)
+        s.set_slices(slices)
+        want = ob.scan_frames(p, mv, off, sd)
+        seen.append(int(want.sum()))
+        host = torch.empty(256, dtype=torch.uint8).pin_memory()
+        assert host.data_ptr() % 128 == 0
+        flags = host[:90]
+        for fill in (7, 9):
+            host.fill_(fill)
+            s.check_frames_device(d_mv, d_off, d_sd, flags)
+            torch.cuda.synchronize()
+            assert np.array_equal(flags.numpy(), want) and int(host[90]) == fill, (s.plan, "40-byte records")
+            host.fill_(fill)
+            s.check_frames_device_compact(d_rec, d_off, d_sd, flags)
+            torch.cuda.synchronize()
+            assert np.array_equal(flags.numpy(), want) and int(host[90]) == fill, (s.plan, "compact records")
+    assert 0 < seen[0] < 90 and 0 < seen[1] < 90          # (the 1080p stream on the 960x540 grid of the third case never reaches 4 votes)
