@@ -123,3 +123,30 @@ def test_pack_records_known_answer():
     assert got.dtype == m.COMPACT_DTYPE and got.itemsize == 8
     assert got["src_x"].tolist() == [1, -2, 32767] and got["dst_y"].tolist() == [8, -9, 10]
     assert got.view(np.uint8).reshape(3, 8).tobytes() == raw[:, 6:14].tobytes()
+
+
+def test_every_environment_knob_is_in_the_headers_table():
+    """include/mtgpu.h "Environment": one table for every MTGPU_* variable the library and the C++ host layer read,
+    in the class in which the code reads it — supported knobs through env_int() / getenv (every build), experiment
+    knobs through exp_int() (csrc/knobs.h: constants unless built with -DMTGPU_EXPERIMENTS)."""
+    import re
+    csrc = os.path.join(os.path.dirname(m.LIB_PATH), "csrc")
+    files = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".cpp", ".h"))]
+    files += [os.path.join(csrc, "host", f) for f in os.listdir(os.path.join(csrc, "host"))]
+    supported, experiments = set(), set()
+    for path in files:
+        text = open(path).read()
+        experiments |= set(re.findall(r'exp_int\("(MTGPU_[A-Z0-9_]+)"', text))
+        supported |= set(re.findall(r'(?:env_int|env_i|getenv)\("(MTGPU_[A-Z0-9_]+)"', text))
+    header = open(os.path.join(ROOT, "include", "mtgpu.h")).read()
+    table = header[header.index(" * Environment (read once"):header.index("#ifndef MTGPU_H")]
+    exp_part = table[table.index("experiments   "):]
+    sup_part = table[:table.index("experiments   ")]
+    listed = lambda part: set(re.findall(r"MTGPU_[A-Z0-9_]+", part.replace("MTGPU_INJECT_SUBMIT_FAIL / _GROW_FAIL / _COLLECT_FAIL",
+                                                                           "MTGPU_INJECT_SUBMIT_FAIL MTGPU_INJECT_GROW_FAIL MTGPU_INJECT_COLLECT_FAIL")))
+    assert experiments and supported and not (experiments & supported - {"MTGPU_FORCE_BLOCK"})
+    assert experiments <= listed(exp_part), sorted(experiments - listed(exp_part))
+    assert supported <= listed(sup_part) | {"MTGPU_LIBRARY"}, sorted(supported - listed(sup_part))
+    # nothing is advertised that no code reads (MTGPU_FORCE_BLOCK appears in both classes: 512 | 1024 always, 256 in the experiments build)
+    assert listed(exp_part) - {"MTGPU_FORCE_BLOCK"} <= experiments, sorted(listed(exp_part) - experiments)
+    assert listed(sup_part) <= supported, sorted(listed(sup_part) - supported)
