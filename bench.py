@@ -761,7 +761,7 @@ def _run_rank(a):
             torch.cuda.synchronize()
             times[name] += [c0.elapsed_time(c1) for c0, c1 in evs]
     for name, t in times.items():
-        sweep[name] = nbytes / (float(np.mean(t)) * 1e-3) / 1e9
+        sweep[name] = nbytes / (max(float(np.mean(t)), 1e-6) * 1e-3) / 1e9       # (a buffer smaller than one chunk launches nothing)
     # ... and the scan itself once more, timed the same way in the same phase of the run (clocks and the memory
     # system's state drift over a run: the timed loop ran seconds earlier)
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
@@ -770,7 +770,7 @@ def _run_rank(a):
         scanner.check_frames_device(d_mv, d_off, None, flag_bufs[0])
         c1.record()
     torch.cuda.synchronize()
-    scan_in_sweep = alg_bytes / (float(np.mean([c0.elapsed_time(c1) for c0, c1 in evs])) * 1e-3) / 1e9
+    scan_in_sweep = alg_bytes / (max(float(np.mean([c0.elapsed_time(c1) for c0, c1 in evs])), 1e-6) * 1e-3) / 1e9
     read_ceiling_best = max(sweep, key=sweep.get)
     read_ceiling = sweep[read_ceiling_best]
     flags_host = d_flags.cpu().numpy()
