@@ -747,7 +747,8 @@ def _run_rank(a):
     for shape, sname, chunks, idle in ((2, "12of40+arith", (frame_bytes, 1280 * 1024), 30), (2, "12of40+arith", (frame_bytes, 1280 * 1024), 0),
                                        (3, "12of40+arith+lds", (frame_bytes,), 30), (1, "12of40", (1280 * 1024, 5 * 1024 * 1024), 0),
                                        (0, "16B", (1280 * 1024, 5 * 1024 * 1024), 0)):
-        configs += [(f"{sname}/{chunk}" + (f"/idle{idle}" if idle else ""), shape, chunk, idle) for chunk in chunks]
+        configs += [(f"{sname}/{chunk}" + (f"/idle{idle}" if idle else ""), shape, chunk, idle) for chunk in chunks
+                    if nbytes >= 256 * chunk]        # (a test-sized batch calibrates nothing: at least a workgroup per CU)
     times = {name: [] for name, _, _, _ in configs}
     for order in (configs, configs[::-1]):       # two passes in opposite orders: no configuration owes its figure to its place
         for name, shape, chunk, idle in order:
@@ -771,8 +772,8 @@ def _run_rank(a):
         c1.record()
     torch.cuda.synchronize()
     scan_in_sweep = alg_bytes / (max(float(np.mean([c0.elapsed_time(c1) for c0, c1 in evs])), 1e-6) * 1e-3) / 1e9
-    read_ceiling_best = max(sweep, key=sweep.get)
-    read_ceiling = sweep[read_ceiling_best]
+    read_ceiling_best = max(sweep, key=sweep.get) if sweep else None
+    read_ceiling = sweep[read_ceiling_best] if sweep else None
     flags_host = d_flags.cpu().numpy()
 
     # what each rank held and did, gathered for the driver (N = 1: one entry)
@@ -837,7 +838,7 @@ def _run_rank(a):
                                                  "(load shape / bytes per workgroup [/ every n-th workgroup idle])",
                      "read_ceiling_sweep_GBps": {k_: round(v_, 1) for k_, v_ in sweep.items()},
                      "scan_rate_next_to_the_sweep_GBps": scan_in_sweep,
-                     "frac_of_measured_ceiling": scan_in_sweep / read_ceiling})
+                     "frac_of_measured_ceiling": scan_in_sweep / read_ceiling if read_ceiling else None})
         line = {
             "metric": "MV-scan frames/sec at 1080p grid" if a.workload.startswith("1080p") else "MV-scan frames/sec",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
