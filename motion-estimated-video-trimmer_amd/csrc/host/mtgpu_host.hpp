@@ -165,6 +165,7 @@ inline BatchSizing default_batch_sizing(int n_videos, int n_devices, int budget,
 // Anything that is not a list of non-negative numbers and ranges throws std::invalid_argument.
 inline std::vector<int> parse_cpu_list(const std::string &text) {
   std::vector<int> out;
+  std::vector<bool> seen;
   const char *p = text.c_str();
   auto skip = [&] { while (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r') ++p; };
   auto number = [&]() -> long {
@@ -183,8 +184,9 @@ inline std::vector<int> parse_cpu_list(const std::string &text) {
     long hi = lo;
     if (*p == '-') { ++p; hi = number(); }
     if (hi < lo) throw std::invalid_argument("cpu list: descending range");
+    if ((size_t)hi >= seen.size()) seen.resize((size_t)hi + 1, false);       // (a bitmap: "0-1048576" must not cost n^2 look-ups)
     for (long c = lo; c <= hi; ++c)
-      if (std::find(out.begin(), out.end(), (int)c) == out.end()) out.push_back((int)c);
+      if (!seen[(size_t)c]) { seen[(size_t)c] = true; out.push_back((int)c); }
     if (*p == ',') { ++p; skip(); if (!*p) throw std::invalid_argument("cpu list: trailing comma"); }
     else if (*p) throw std::invalid_argument("cpu list: ',' expected");
   }
