@@ -34,10 +34,10 @@
  *  `d_flags` in host memory should share its lines with nothing the HOST writes while the call is in flight — give
  *  it lines of its own (128-byte aligned), as the pipe does.  Results in host memory are complete when
  *  an event recorded behind the call on `stream` (hipEventReleaseToSystem) or a stream synchronisation has passed.
- *  NOT supported, and not checked: host memory page-locked with hipHostRegister (a user-pointer mapping: its pages
- *  are not pinned by the driver, the kernel driver re-validates the mapping when the OS touches them — the one wrong
- *  result this library ever returned came from such staging), hipMallocManaged memory that is not
- *  resident on the device, and memory of another device.
+ *  NOT supported, and not checked: host memory page-locked with hipHostRegister (a user-pointer mapping of pages the
+ *  process owns, which the kernel driver re-validates whenever the OS changes the page tables underneath — the one
+ *  wrong result this library ever returned came from such staging), hipMallocManaged memory that is
+ *  not resident on the device, and memory of another device.
  *
  * Environment (read once, at mtgpu_create / at the first use; csrc/knobs.h)
  *    production    MTGPU_CHECK_OFFSETS=1   device entry points verify frame_off first (one sync per call)
