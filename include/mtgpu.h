@@ -49,7 +49,7 @@
  *                  MTGPU_INJECT_SUBMIT_FAIL / _GROW_FAIL / _COLLECT_FAIL / MTGPU_INJECT_ONCE (pipe error paths)
  *    experiments   MTGPU_VARIANT, MTGPU_ALIGN, MTGPU_PREFETCH, MTGPU_DEFAULT_POOL, MTGPU_PIPE_STREAMS, MTGPU_PIPE_EAGER,
  *                  MTGPU_EVENT_BLOCKING, MTGPU_MAX_TILE_KB, MTGPU_BAND_LDS_KB, MTGPU_MIN_LDS_KB, MTGPU_FORCE_CHUNK,
- *                  MTGPU_PACK_NT, MTGPU_PACK_PREFETCH, MTGPU_FORCE_BLOCK=256: A/B switches whose losing side is
+ *                  MTGPU_PACK_NT, MTGPU_PACK_PREFETCH, MTGPU_XCD_MIX, MTGPU_FORCE_BLOCK=256: A/B switches whose losing side is
  *                  documented; IGNORED by this library unless it was built with
  *                  `make -C csrc experiments` (mtgpu_version() then ends in "+experiments")
  */

@@ -264,6 +264,7 @@ int make_plan(mtgpu_ctx *c, int lds_max, int cu_count) {
   k.slices = 1;
   k.group = 1;
   k.sys_flags = 0;                                            // per launch: launch_scan_on
+  k.xcd_mix = exp_int("MTGPU_XCD_MIX", 0) != 0 ? 1 : 0;
   k.align_lines = exp_int("MTGPU_ALIGN", 1) != 0 ? 1 : 0;     // experiments: 0 = streams start wherever the frame starts
   k.prefetch = exp_int("MTGPU_PREFETCH", 1) != 0 ? 1 : 0;      // experiments: 0 switches the next-frame prefetch off
   c->group_request = env_int("MTGPU_GROUP", 0);

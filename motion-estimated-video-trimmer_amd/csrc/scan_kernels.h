@@ -28,6 +28,8 @@ struct ScanK {
   int group;               // consecutive work items per workgroup (>= 1; > 1 only with slices == 1)
   int align_lines;         // 40-byte records: peel < 16 head records so that the stream starts on a 128-byte line
   int prefetch;            // compact records, group > 1: issue the next frame's first step before this frame's cluster test
+  int xcd_mix;             // workgroup -> work item: the 8 workgroups of an octet (one per XCD) take the octet's 8 items rotated
+                           // by a hash of the octet's index, so that no period of empty frames falls on the same XCDs
   int sys_flags;           // flags do not live in device memory (pinned host memory: the pipe's zero-copy staging, a caller's
                            // hipHostMalloc'ed buffer): result bytes leave with system-scope write-through stores
 };

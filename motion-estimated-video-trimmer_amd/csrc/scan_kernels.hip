@@ -892,7 +892,12 @@ __global__ __launch_bounds__(BLOCK) void scan_frames_kernel(
     unsigned int item0, unsigned int n_items, ScanK k, unsigned char *__restrict__ flags,
     unsigned int *spill_q, unsigned int *slice_ws, unsigned int *tickets) {
   extern __shared__ __attribute__((aligned(16))) unsigned int lds[];
-  const unsigned int first = item0 + blockIdx.x * (unsigned int)k.group;
+  unsigned int wg = blockIdx.x;
+  if (k.xcd_mix) {                             // only whole octets of this launch are permuted (a bijection inside each)
+    const unsigned int q = wg >> 3;
+    if (((q + 1u) << 3) <= gridDim.x) wg = (q << 3) | ((wg + ((q * 0x9E3779B1u) >> 29)) & 7u);
+  }
+  const unsigned int first = item0 + wg * (unsigned int)k.group;
   NextStep<UNROLL> ns;
   ns.have = false;
   ns.frame = 0u;
