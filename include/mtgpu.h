@@ -149,6 +149,14 @@ int mtgpu_plan_preview(const mt_scan_params *params, int lds_bytes_per_workgroup
  * Results never depend on it. */
 int mtgpu_set_slices(mtgpu_ctx *ctx, int slices);
 
+/* Which frame a workgroup scans: 0 (default) = frames in order, 1 = the 8 frames of every octet rotated by a hash of the
+ * octet's index.  The chip deals the workgroups of a launch to its 8 XCDs in turn, so frames WITHOUT records (I-frames:
+ * their workgroups leave at once) whose period shares a factor with 8 — a stream with a key frame every 8, 16, 32
+ * frames — leave whole XCDs without work (period 8: -8 %); the rotation spreads them over all XCDs (6531 -> 7013 GB/s
+ * at period 8, 6874 -> 7059 at 16) and costs ~0.6 % on streams where order was fine.  A host that knows
+ * its streams' GOP sets it once; results never depend on it. */
+int mtgpu_set_frame_order(mtgpu_ctx *ctx, int mixed);
+
 /* Calibration only (bench.py): stream `bytes` of a device buffer and discard them — what a kernel that ONLY reads
  * reaches on that buffer.  shape 0: 16 contiguous bytes per lane; 1: the scan's own access (bytes 4..15 of every
  * 40-byte record); 2: shape 1 plus the scan's arithmetic on a record that does not vote; 3: shape 2 inside the scan's

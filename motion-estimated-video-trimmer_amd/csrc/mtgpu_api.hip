@@ -730,6 +730,13 @@ int mtgpu_debug_read_ceiling(mtgpu_ctx *c, const void *d_buf, uint64_t bytes, vo
   return mtgpu_debug_read_ceiling_shape(c, d_buf, bytes, 0, 0, 0, stream);
 }
 
+int mtgpu_set_frame_order(mtgpu_ctx *c, int mixed) {
+  if (!c) return fail(MT_ERR_INVALID, "ctx is NULL");
+  if (mixed != 0 && mixed != 1) return fail(MT_ERR_INVALID, "mixed must be 0 (frames in order) or 1 (rotated inside octets)");
+  c->k.xcd_mix = mixed;
+  return MT_OK;
+}
+
 int mtgpu_set_slices(mtgpu_ctx *c, int slices) {
   if (!c) return fail(MT_ERR_INVALID, "ctx is NULL");
   if (slices != 0 && slices != 1 && slices != 2 && slices != 4 && slices != 8)

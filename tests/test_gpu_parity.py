@@ -1566,3 +1566,47 @@ def test_device_entry_points_with_flags_in_pinned_host_memory(gpu_scanner_factor
             torch.cuda.synchronize()
             assert np.array_equal(flags.numpy(), want) and int(host[90]) == fill, (s.plan, "compact records")
     assert 0 < seen[0] < 90 and 0 < seen[1] < 90          # (the 1080p stream on the 960x540 grid of the third case never reaches 4 votes)
+
+
+@pytest.mark.parametrize("slices,group,chunk", [(0, "", ""), (2, "", ""), (0, "3", ""), (0, "", "5"), (0, "2", "7")])
+def test_frame_order_never_changes_results(gpu_scanner_factory, monkeypatch, slices, group, chunk):
+    """mtgpu_set_frame_order(ctx, 1): the 8 work items of every octet of workgroups are taken in an order rotated by a
+    hash of the octet's index (empty frames with a period of 8, 16, 32 ... would otherwise leave whole XCDs idle).
+    A permutation of who scans what: every flag as before — frames with and without records at periods 8 and 30, a batch
+    that is not a multiple of 8, frame slices, several frames per workgroup, launches cut into chunks of 5 and 7
+    workgroups (only whole octets of a launch are permuted), 40-byte and compact records."""
+    import torch
+    for k_, v_ in (("MTGPU_GROUP", group), ("MTGPU_ITEM_CHUNK", chunk)):
+        if v_:
+            monkeypatch.setenv(k_, v_)
+    p = ob.params_from_config(1920, 1080, vectors_needed=2, clusters_needed=1)
+    s = gpu_scanner_factory(p)
+    for k_ in ("MTGPU_GROUP", "MTGPU_ITEM_CHUNK"):
+        monkeypatch.delenv(k_, raising=False)
+    s.set_slices(slices)
+    rng = np.random.RandomState(11)
+    frames = []
+    for f in range(203):                                    # 203 = 25 octets + 3
+        if f % 8 == 0 or f % 30 == 0:
+            frames.append(None if f % 16 == 0 else np.zeros(0, dtype=m.MV_DTYPE))
+            continue
+        n = int(rng.choice([1, 40, 700, 3000]))
+        mv = np.zeros(n, dtype=m.MV_DTYPE)
+        mv["dst_x"], mv["dst_y"] = rng.randint(0, 1920, size=n), rng.randint(0, 1080, size=n)
+        mv["src_x"], mv["src_y"] = mv["dst_x"] - rng.choice([0, 1, 5], size=n), mv["dst_y"]
+        if f % 3 == 0:                                      # a cluster: two votes in each of two neighbouring cells
+            for q, (gx, gy) in enumerate(((50, 30), (50, 30), (51, 30), (51, 30))):
+                if q < n:
+                    mv["dst_x"][q], mv["dst_y"][q], mv["src_x"][q], mv["src_y"][q] = gx * 16 + 8, gy * 16 + 8, gx * 16, gy * 16 + 8
+        frames.append(mv)
+    b = m.FrameBatch.from_frames(frames)
+    want = ob.scan_frames(p, b.mv, b.frame_off, b.has_sd)
+    assert 20 < want.sum() < 150
+    rec8 = torch.from_numpy(m.pack_records(b.mv).view(np.uint8).copy()).cuda()
+    d_off = torch.from_numpy(b.frame_off.astype(np.int64)).cuda()
+    d_sd = torch.from_numpy(b.has_sd.astype(np.uint8)).cuda()
+    for mixed in (True, False, True):
+        s.set_frame_order(mixed)
+        assert np.array_equal(s.check_frames(b), want), mixed
+        assert np.array_equal(s.check_frames_device_compact(rec8, d_off, d_sd).cpu().numpy(), want), (mixed, "compact")
+    s.set_frame_order(False)
