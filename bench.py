@@ -519,6 +519,42 @@ def other_workloads(dev, distinct, arena=None):
             torch.cuda.empty_cache()
         except Exception as e:      # informational leg: never take the headline down
             out.append({"workload": f"1080p compact records, {cframes} frames", "error": repr(e)})
+    # frames without records whose period shares a factor with 8 leave whole XCDs without work (the chip deals workgroups
+    # to its 8 XCDs in turn): the headline workload with a key frame every 8 frames instead of every 30, frames in order
+    # against mtgpu_set_frame_order(ctx, 1)
+    try:
+        orig = globals()["make_spec"]
+
+        def gop8(workload, seed):
+            spec, rest = orig(workload, seed)
+            spec.gop = 8
+            return spec, rest
+        globals()["make_spec"] = gop8
+        try:
+            w = build_workload("1080p_dense8x8", "code_defaults", 4096, 64, 1000, dev, arena)
+        finally:
+            globals()["make_spec"] = orig
+        rates = {}
+        ref = None
+        for name, mixed in (("in_order", False), ("rotated", True), ("in_order_again", False), ("rotated_again", True)):
+            w["scanner"].set_frame_order(mixed)
+            ms = time_scan_only(w, 10)
+            fl = w["d_flags"].cpu().numpy()
+            ref = fl if ref is None else ref
+            assert np.array_equal(fl, ref), "frame order changed a flag"
+            rates[name] = w["alg_bytes"] / (ms * 1e-3) / 1e9
+        w["scanner"].set_frame_order(False)
+        out.append({"workload": "1080p_dense8x8 with a key frame (no records) every 8 frames, 4096 frames: frames in order vs "
+                                "mtgpu_set_frame_order(ctx, 1)", "achieved_GBps": rates,
+                    "frac": max(rates.values()) / HBM_PEAK_GBS, "gain_of_rotation": (rates["rotated"] + rates["rotated_again"]) /
+                    (rates["in_order"] + rates["in_order_again"])})
+        w["scanner"].close()
+        del w
+        torch.cuda.empty_cache()
+    except AssertionError:
+        raise
+    except Exception as e:          # informational leg
+        out.append({"workload": "frame order A/B (key frame every 8 frames)", "error": repr(e)})
     return out
 
 
