@@ -239,7 +239,7 @@ def make_spec(workload, seed):
 ARENA_BYTES = 20_800_000_000     # one record arena for every 21 GB leg of a run (see build_workload)
 
 
-def build_workload(workload, params_name, frames, distinct, seed, dev, arena=None):
+def build_workload(workload, params_name, frames, distinct, seed, dev, arena=None, gop=None):
     """`distinct` generated frames tiled to `frames`, resident on `dev`.  `arena` (uint8 device tensor): the
     records are tiled INTO it instead of into a new allocation — every leg of a bench run then reads the same
     physical memory as the headline (where a 21 GB buffer lands after others were freed moved a leg by 2-5 %)."""
@@ -247,6 +247,8 @@ def build_workload(workload, params_name, frames, distinct, seed, dev, arena=Non
     import mvtrim_amd as m
     from mvtrim_amd import synth
     spec, (W, H, gridkw) = make_spec(workload, seed=seed)
+    if gop is not None:              # key-frame period (frames without side data); default: the workload's own (30)
+        spec.gop = gop
     spec.events = synth.scripted_events(spec, distinct)
     if os.environ.get("AB_PAN") == "1":      # developer scripts only: every MV above the threshold ("camera pan")
         spec.events = [synth.Event(0, distinct, 0, 0, spec.cells_x, spec.cells_y, 9, 3)]
@@ -462,6 +464,23 @@ def replayed_traffic(workload, params_name, frames):
         f"{rec.get('collected') or 'round 2'}")
 
 
+def load_calib():
+    """libmtgpu_calib.so (csrc/calib/): read-only kernels in the scan's load shapes, for the measured read ceiling.
+    A library of its own — the product (libmtgpu.so) carries no calibration code.  Returns a callable
+    (device, ptr, bytes, shape, chunk, lds_bytes, idle_every, stream) that raises on error."""
+    import ctypes as C
+    lib = C.CDLL(os.path.join(ROOT, "motion-estimated-video-trimmer_amd", "libmtgpu_calib.so"))
+    fn = lib.mtcalib_read_ceiling
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_int, C.c_void_p, C.c_uint64, C.c_int, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p]
+    lib.mtcalib_last_error.restype = C.c_char_p
+
+    def call(device, ptr, nbytes, shape, chunk, lds_bytes, idle_every, stream):
+        if fn(device, ptr, nbytes, shape, chunk, lds_bytes, idle_every, stream) != 0:
+            raise RuntimeError("mtcalib_read_ceiling: " + lib.mtcalib_last_error().decode())
+    return call
+
+
 def roofline_of(alg_bytes, kern_ms):
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
     return {"bound": "hbm", "kernel": "scan_frames_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
@@ -519,42 +538,29 @@ def other_workloads(dev, distinct, arena=None):
             torch.cuda.empty_cache()
         except Exception as e:      # informational leg: never take the headline down
             out.append({"workload": f"1080p compact records, {cframes} frames", "error": repr(e)})
-    # frames without records whose period shares a factor with 8 leave whole XCDs without work (the chip deals workgroups
-    # to its 8 XCDs in turn): the headline workload with a key frame every 8 frames instead of every 30, frames in order
-    # against mtgpu_set_frame_order(ctx, 1)
+    # key frames: a frame without side data never gets a workgroup (the work list, scan_kernels.hip plan_*), so the rate
+    # must not depend on where such frames fall.  The headline workload's frames with a key frame every 8 frames
+    # (round 5, one workgroup per frame: one of the 8 XCDs without work, -4.5 .. -8 %) and with none at all.
     try:
-        orig = globals()["make_spec"]
-
-        def gop8(workload, seed):
-            spec, rest = orig(workload, seed)
-            spec.gop = 8
-            return spec, rest
-        globals()["make_spec"] = gop8
-        try:
-            w = build_workload("1080p_dense8x8", "code_defaults", 4096, 64, 1000, dev, arena)
-        finally:
-            globals()["make_spec"] = orig
         rates = {}
-        ref = None
-        for name, mixed in (("in_order", False), ("rotated", True), ("in_order_again", False), ("rotated_again", True)):
-            w["scanner"].set_frame_order(mixed)
+        for name, gop in (("no_key_frames", 0), ("key_frame_every_8", 8), ("no_key_frames_again", 0), ("key_frame_every_8_again", 8)):
+            w = build_workload("1080p_dense8x8", "code_defaults", 4096 if gop == 0 else 4680, 64, 1000, dev, arena, gop=gop)
             ms = time_scan_only(w, 10)
             fl = w["d_flags"].cpu().numpy()
-            ref = fl if ref is None else ref
-            assert np.array_equal(fl, ref), "frame order changed a flag"
+            assert np.array_equal(fl, np.tile(fl[:64], w["reps"])[: w["frames"]]), "flags are not tile-periodic"
             rates[name] = w["alg_bytes"] / (ms * 1e-3) / 1e9
-        w["scanner"].set_frame_order(False)
-        out.append({"workload": "1080p_dense8x8 with a key frame (no records) every 8 frames, 4096 frames: frames in order vs "
-                                "mtgpu_set_frame_order(ctx, 1)", "achieved_GBps": rates,
-                    "frac": max(rates.values()) / HBM_PEAK_GBS, "gain_of_rotation": (rates["rotated"] + rates["rotated_again"]) /
-                    (rates["in_order"] + rates["in_order_again"])})
-        w["scanner"].close()
-        del w
-        torch.cuda.empty_cache()
+            w["scanner"].close()
+            del w
+            torch.cuda.empty_cache()
+        out.append({"workload": "1080p_dense8x8, 4096 frames with records: no key frames vs a key frame (no side data) "
+                                "every 8 frames (4680 frames)", "achieved_GBps": rates,
+                    "frac": min(rates.values()) / HBM_PEAK_GBS,
+                    "key_frames_every_8_over_none": (rates["key_frame_every_8"] + rates["key_frame_every_8_again"]) /
+                    (rates["no_key_frames"] + rates["no_key_frames_again"])})
     except AssertionError:
         raise
     except Exception as e:          # informational leg
-        out.append({"workload": "frame order A/B (key frame every 8 frames)", "error": repr(e)})
+        out.append({"workload": "key-frame period A/B (every 8 frames vs none)", "error": repr(e)})
     return out
 
 
@@ -774,7 +780,7 @@ def _run_rank(a):
     kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in zip(ev0, ev1)]))
     # calibration (outside the timed region): kernels that ONLY read the same record buffer — both load shapes, three
     # chunk sizes, 20 launches back to back each (the regime of the timed loop); the ceiling is the best of them
-    lib = m.load_library()
+    calib = load_calib()
     st = torch.cuda.current_stream(dev).cuda_stream
     nbytes = (d_mv.numel() // 16) * 16
     frame_bytes = 40 * int(spec.records_per_frame)                                # a P-frame of this workload (ragged workloads: its nominal size)
@@ -789,11 +795,11 @@ def _run_rank(a):
     for order in (configs, configs[::-1]):       # two passes in opposite orders: no configuration owes its figure to its place
         for name, shape, chunk, idle in order:
             for _ in range(2):
-                m._abi.check(lib.mtgpu_debug_read_ceiling_shape(scanner._ctx, d_mv.data_ptr(), nbytes, shape, chunk, idle, st))
+                calib(dev.index, d_mv.data_ptr(), nbytes, shape, chunk, scanner.plan["lds_bytes"], idle, st)
             evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
             for c0, c1 in evs:           # an event pair around every launch, exactly as the scan kernel is timed
                 c0.record()
-                m._abi.check(lib.mtgpu_debug_read_ceiling_shape(scanner._ctx, d_mv.data_ptr(), nbytes, shape, chunk, idle, st))
+                calib(dev.index, d_mv.data_ptr(), nbytes, shape, chunk, scanner.plan["lds_bytes"], idle, st)
                 c1.record()
             torch.cuda.synchronize()
             times[name] += [c0.elapsed_time(c1) for c0, c1 in evs]
@@ -908,12 +914,14 @@ def _run_rank(a):
         dist.destroy_process_group()
         stage("done")
         import faulthandler
-        hang["file"] = None
         faulthandler.cancel_dump_traceback_later()
+        if hang["file"] is not None:
+            hang["file"].close()
+            hang["file"] = None
         try:                                   # the hang log of a run that did not hang is empty: drop it
-            hang = rank_log_path(rank) + ".hang.log"
-            if os.path.exists(hang) and os.path.getsize(hang) == 0:
-                os.remove(hang)
+            hang_path = rank_log_path(rank) + ".hang.log"
+            if os.path.exists(hang_path) and os.path.getsize(hang_path) == 0:
+                os.remove(hang_path)
         except OSError:
             pass
     scanner.close()

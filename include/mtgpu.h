@@ -47,11 +47,8 @@
  *    tests only    MTGPU_FORCE_FB=32|1|2|4|8|108, MTGPU_FORCE_BLOCK=512|1024, MTGPU_FORCE_SLICES, MTGPU_GROUP,
  *                  MTGPU_ITEM_CHUNK, MTGPU_MERGE_LARGE_MIN (reach every kernel form on small inputs),
  *                  MTGPU_INJECT_SUBMIT_FAIL / _GROW_FAIL / _COLLECT_FAIL / MTGPU_INJECT_ONCE (pipe error paths)
- *    experiments   MTGPU_VARIANT, MTGPU_ALIGN, MTGPU_PREFETCH, MTGPU_DEFAULT_POOL, MTGPU_PIPE_STREAMS, MTGPU_PIPE_EAGER,
- *                  MTGPU_EVENT_BLOCKING, MTGPU_MAX_TILE_KB, MTGPU_BAND_LDS_KB, MTGPU_MIN_LDS_KB, MTGPU_FORCE_CHUNK,
- *                  MTGPU_PACK_NT, MTGPU_PACK_PREFETCH, MTGPU_XCD_MIX, MTGPU_FORCE_BLOCK=256: A/B switches whose losing side is
- *                  documented; IGNORED by this library unless it was built with
- *                  `make -C csrc experiments` (mtgpu_version() then ends in "+experiments")
+ *  (A/B switches of measurements exist only in the experiments build, `make -C csrc experiments`; this library
+ *  ignores them.  Their table: csrc/knobs.h.)
  */
 #ifndef MTGPU_H
 #define MTGPU_H
@@ -148,25 +145,6 @@ int mtgpu_plan_preview(const mt_scan_params *params, int lds_bytes_per_workgroup
  * when a batch has too few frames to fill the chip and the frames are large), or 1, 2, 4, 8.
  * Results never depend on it. */
 int mtgpu_set_slices(mtgpu_ctx *ctx, int slices);
-
-/* Which frame a workgroup scans: 0 (default) = frames in order, 1 = the 8 frames of every octet rotated by a hash of the
- * octet's index.  The chip deals the workgroups of a launch to its 8 XCDs in turn, so frames WITHOUT records (I-frames:
- * their workgroups leave at once) whose period shares a factor with 8 — a stream with a key frame every 8, 16, 32
- * frames — leave whole XCDs without work (period 8: -8 %); the rotation spreads them over all XCDs (6531 -> 7013 GB/s
- * at period 8, 6874 -> 7059 at 16) and costs ~0.6 % on streams where order was fine.  A host that knows
- * its streams' GOP sets it once; results never depend on it. */
-int mtgpu_set_frame_order(mtgpu_ctx *ctx, int mixed);
-
-/* Calibration only (bench.py): stream `bytes` of a device buffer and discard them — what a kernel that ONLY reads
- * reaches on that buffer.  shape 0: 16 contiguous bytes per lane; 1: the scan's own access (bytes 4..15 of every
- * 40-byte record); 2: shape 1 plus the scan's arithmetic on a record that does not vote; 3: shape 2 inside the scan's
- * LDS phases (tile zeroed first, walked once at the end).  chunk_bytes: contiguous bytes per 512-thread workgroup
- * (0 = 1.25 MiB; one frame's bytes makes shapes 1-3 the scan kernel with the votes taken out).  idle_every > 1: every
- * idle_every-th workgroup has nothing to do, as the frames without records of a stream.  bench.py reports the best
- * of a small sweep as the measured ceiling.  Asynchronous on `stream`.  mtgpu_debug_read_ceiling = shape 0, defaults. */
-int mtgpu_debug_read_ceiling_shape(mtgpu_ctx *ctx, const void *d_buf, uint64_t bytes, int shape, uint64_t chunk_bytes,
-                                   uint32_t idle_every, void *stream);
-int mtgpu_debug_read_ceiling(mtgpu_ctx *ctx, const void *d_buf, uint64_t bytes, void *stream);
 
 /*
  * check_frame() over a device-resident batch — replaces the per-frame call at

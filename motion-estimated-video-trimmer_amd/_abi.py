@@ -91,9 +91,6 @@ ABI = {
     "mtgpu_get_plan": (C.c_int, [C.c_void_p, C.POINTER(PlanC)]),
     "mtgpu_plan_preview": (C.c_int, [C.POINTER(ScanParamsC), C.c_int, C.c_int, C.POINTER(PlanC)]),
     "mtgpu_set_slices": (C.c_int, [C.c_void_p, C.c_int]),
-    "mtgpu_set_frame_order": (C.c_int, [C.c_void_p, C.c_int]),
-    "mtgpu_debug_read_ceiling": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
-    "mtgpu_debug_read_ceiling_shape": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_uint64, C.c_uint32, C.c_void_p]),
     "mtgpu_scan_frames_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p,
                                            C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     "mtgpu_scan_frames_device_compact": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p,

@@ -4,6 +4,7 @@
 // the CPU (no fallback: without a usable device every compute call fails).
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cctype>
 #include <cmath>
 #include <cstdarg>
@@ -78,7 +79,8 @@ struct mtgpu_ctx {
   int logical_device = 0;  // what the caller asked for (differs only under MTGPU_ALIAS_DEVICES)
   hipStream_t stream;    // private stream of the host-pointer entry points
   int variant = 0;       // MTGPU_VARIANT experiment knob
-  int slices_request = 0;  // 0 = auto, else 1/2/4/8 (mtgpu_set_slices, MTGPU_FORCE_SLICES)
+  std::atomic<int> slices_request{0};  // 0 = auto, else 1/2/4/8 (mtgpu_set_slices, MTGPU_FORCE_SLICES): read once per launch,
+                                       // may be set while other threads scan through this context
   int wide_chunk_rows = 0, wide_lds_bytes = 0;   // single-workgroup-per-CU layout (see make_plan)
   int item_chunk = 0;    // MTGPU_ITEM_CHUNK (tests): workgroups per kernel launch, 0 = 2^30
   int lds_max = 0;       // device limit of LDS per workgroup
@@ -259,12 +261,12 @@ int make_plan(mtgpu_ctx *c, int lds_max, int cu_count) {
   c->variant = exp_int("MTGPU_VARIANT", 0);
   {
     const int fs = env_int("MTGPU_FORCE_SLICES", 0);
-    c->slices_request = (fs == 1 || fs == 2 || fs == 4 || fs == 8) ? fs : 0;
+    c->slices_request.store((fs == 1 || fs == 2 || fs == 4 || fs == 8) ? fs : 0, std::memory_order_relaxed);
   }
   k.slices = 1;
   k.group = 1;
   k.sys_flags = 0;                                            // per launch: launch_scan_on
-  k.xcd_mix = exp_int("MTGPU_XCD_MIX", 0) != 0 ? 1 : 0;
+  k.resident = std::min(std::max(exp_int("MTGPU_RESIDENT", 0), 0), 16);   // experiments: ticketed resident workgroups per CU
   k.align_lines = exp_int("MTGPU_ALIGN", 1) != 0 ? 1 : 0;     // experiments: 0 = streams start wherever the frame starts
   k.prefetch = exp_int("MTGPU_PREFETCH", 1) != 0 ? 1 : 0;      // experiments: 0 switches the next-frame prefetch off
   c->group_request = env_int("MTGPU_GROUP", 0);
@@ -290,7 +292,7 @@ int make_plan(mtgpu_ctx *c, int lds_max, int cu_count) {
 // workgroup per CU and keeps >= 32768 records (1.3 MB) per slice.
 int choose_slices(const mtgpu_ctx *c, uint64_t n_records, uint32_t n_frames) {
   if (c->k.bands != 1) return 1;
-  int s = c->slices_request;
+  int s = c->slices_request.load(std::memory_order_relaxed);
   if (s == 0) {                                               // auto
     const uint64_t cus = (uint64_t)(c->plan.cu_count > 0 ? c->plan.cu_count : 256);
     const uint64_t avg = n_records / (n_frames ? n_frames : 1);
@@ -347,21 +349,24 @@ hipError_t scratch_alloc(mtgpu_ctx *c, void **p, size_t bytes, hipStream_t st) {
 // flags_sys: 1 = d_flags is not device memory (system-scope result stores), 0 = device memory, -1 = ask the runtime
 int launch_scan_on(mtgpu_ctx *c, const void *d_mv, uint64_t n_records, const uint64_t *d_off,
                    const uint8_t *d_sd, uint32_t n_frames, uint8_t *d_flags, hipStream_t st, int rec_bytes = MT_MV_BYTES,
-                   int flags_sys = 0) {
+                   int flags_sys = 0, uint64_t rebase = 0) {
   if (flags_sys < 0) {
     // a caller's pointer (the *_device entry points): device memory takes plain stores; anything else the runtime
     // knows of, or does not know at all, takes the system-scope ones
     hipPointerAttribute_t at;
     std::memset(&at, 0, sizeof at);
-    flags_sys = (hipPointerGetAttributes(&at, d_flags) == hipSuccess && at.type == hipMemoryTypeDevice) ? 0 : 1;
-    (void)hipGetLastError();
+    const hipError_t qe = hipPointerGetAttributes(&at, d_flags);
+    flags_sys = (qe == hipSuccess && at.type == hipMemoryTypeDevice) ? 0 : 1;
+    if (qe != hipSuccess) (void)hipGetLastError();      // only the failed query's own error is cleared
   }
   mtgpu::ScanLaunch L;
   L.rec_bytes = rec_bytes;
   L.lds_max = c->lds_max;
   L.device = c->device;
+  L.cu_count = c->plan.cu_count;
   L.mv = static_cast<const unsigned char *>(d_mv);
   L.n_records = n_records;
+  L.rebase = rebase;
   L.frame_off = reinterpret_cast<const unsigned long long *>(d_off);
   L.has_sd = d_sd;
   L.n_frames = n_frames;
@@ -369,10 +374,11 @@ int launch_scan_on(mtgpu_ctx *c, const void *d_mv, uint64_t n_records, const uin
   L.spill_q = nullptr;
   L.slice_ws = nullptr;
   L.tickets = nullptr;
+  L.plan_ws = nullptr;
   L.k = c->k;
   L.k.sys_flags = flags_sys;
-  L.k.slices = choose_slices(c, n_records, n_frames);
-  L.k.group = choose_group(c, n_records, n_frames, rec_bytes, L.k.slices);
+  L.k.slices = choose_slices(c, n_records - rebase, n_frames);
+  L.k.group = choose_group(c, n_records - rebase, n_frames, rec_bytes, L.k.slices);
   if ((uint64_t)n_frames * (uint64_t)L.k.slices >= (1ull << 32))
     return fail(MT_ERR_INVALID, "%u frames x %d slices: work items must stay below 2^32 per call", n_frames, L.k.slices);
   L.block = c->plan.block_threads;
@@ -387,27 +393,27 @@ int launch_scan_on(mtgpu_ctx *c, const void *d_mv, uint64_t n_records, const uin
   }
   if (c->min_lds_kb > 0) L.lds_bytes = std::max(L.lds_bytes, std::min(c->min_lds_kb * 1024, c->lds_max));
   L.stream = st;
-  void *scratch = nullptr;
-  size_t bytes = 0;
-  if (L.k.bands > 1) bytes = sizeof(unsigned int) * ((size_t)n_records + 4);   // spill queue: a slot per record
+  // launch scratch, one stream-ordered block: [work list + planning counts | spill queue or slice tiles + tickets]
+  const size_t plan_bytes = (mtgpu::plan_scratch_bytes(n_frames) + 255u) & ~(size_t)255u;
+  size_t bytes = plan_bytes;
+  if (L.k.bands > 1) bytes += sizeof(unsigned int) * ((size_t)(n_records - rebase) + 4);   // spill queue: a slot per record
   if (L.k.slices > 1)
-    bytes = sizeof(unsigned int) * ((size_t)n_frames * (size_t)L.k.slices * (size_t)L.k.cnt_words + (size_t)n_frames + 4);
-  if (bytes) {
-    hipError_t e = scratch_alloc(c, &scratch, bytes, st);
-    if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(scan scratch)");
-    if (L.k.bands > 1) L.spill_q = static_cast<unsigned int *>(scratch);
-    if (L.k.slices > 1) {
-      L.slice_ws = static_cast<unsigned int *>(scratch);
-      L.tickets = L.slice_ws + (((size_t)n_frames * (size_t)L.k.slices * (size_t)L.k.cnt_words + 3) & ~(size_t)3);
-    }
+    bytes += sizeof(unsigned int) * ((size_t)n_frames * (size_t)L.k.slices * (size_t)L.k.cnt_words + (size_t)n_frames + 4);
+  void *scratch = nullptr;
+  hipError_t e = scratch_alloc(c, &scratch, bytes, st);
+  if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(scan scratch)");
+  L.plan_ws = scratch;
+  unsigned int *rest = reinterpret_cast<unsigned int *>(static_cast<unsigned char *>(scratch) + plan_bytes);
+  if (L.k.bands > 1) L.spill_q = rest;
+  if (L.k.slices > 1) {
+    L.slice_ws = rest;
+    L.tickets = L.slice_ws + (((size_t)n_frames * (size_t)L.k.slices * (size_t)L.k.cnt_words + 3) & ~(size_t)3);
   }
-  hipError_t e = mtgpu::launch_scan(L);
+  e = mtgpu::launch_scan(L);
   int rc = MT_OK;
   if (e != hipSuccess) rc = hip_fail(e, "scan launch");
-  if (scratch) {
-    hipError_t e2 = hipFreeAsync(scratch, st);
-    if (rc == MT_OK && e2 != hipSuccess) rc = hip_fail(e2, "hipFreeAsync");
-  }
+  hipError_t e2 = hipFreeAsync(scratch, st);
+  if (rc == MT_OK && e2 != hipSuccess) rc = hip_fail(e2, "hipFreeAsync");
   return rc;
 }
 
@@ -711,37 +717,11 @@ int mtgpu_pack_records_with(int impl_flags, const void *mv_bytes, uint64_t n_rec
 
 int mtgpu_pack_selected(void) { return mtgpu::pack_selected(); }
 
-int mtgpu_debug_read_ceiling_shape(mtgpu_ctx *c, const void *d_buf, uint64_t bytes, int shape, uint64_t chunk_bytes,
-                                   uint32_t idle_every, void *stream) {
-  if (!c) return fail(MT_ERR_INVALID, "ctx is NULL");
-  if (!d_buf || ((uintptr_t)d_buf & 15u)) return fail(MT_ERR_INVALID, "buffer must be non-NULL and 16-byte aligned");
-  if (shape < 0 || shape > 3) return fail(MT_ERR_INVALID, "shape must be 0 (16-byte contiguous), 1 (12 of 40 bytes), 2 (1 + the scan's per-record arithmetic) or 3 (2 + the scan's LDS phases)");
-  HIP_TRY(hipSetDevice(c->device));
-  std::lock_guard<std::mutex> lock(c->mu);
-  int rc = c->d_sd.reserve(64);                      // 4-byte sink lives in a staging buffer
-  if (rc != MT_OK) return rc;
-  hipError_t e = mtgpu::launch_read_ceiling(d_buf, bytes, shape, chunk_bytes, (unsigned int)c->plan.lds_bytes, idle_every,
-                                            static_cast<unsigned int *>(c->d_sd.p), static_cast<hipStream_t>(stream));
-  if (e != hipSuccess) return hip_fail(e, "read ceiling launch");
-  return MT_OK;
-}
-
-int mtgpu_debug_read_ceiling(mtgpu_ctx *c, const void *d_buf, uint64_t bytes, void *stream) {
-  return mtgpu_debug_read_ceiling_shape(c, d_buf, bytes, 0, 0, 0, stream);
-}
-
-int mtgpu_set_frame_order(mtgpu_ctx *c, int mixed) {
-  if (!c) return fail(MT_ERR_INVALID, "ctx is NULL");
-  if (mixed != 0 && mixed != 1) return fail(MT_ERR_INVALID, "mixed must be 0 (frames in order) or 1 (rotated inside octets)");
-  c->k.xcd_mix = mixed;
-  return MT_OK;
-}
-
 int mtgpu_set_slices(mtgpu_ctx *c, int slices) {
   if (!c) return fail(MT_ERR_INVALID, "ctx is NULL");
   if (slices != 0 && slices != 1 && slices != 2 && slices != 4 && slices != 8)
     return fail(MT_ERR_INVALID, "slices must be 0 (auto), 1, 2, 4 or 8");
-  c->slices_request = slices;
+  c->slices_request.store(slices, std::memory_order_relaxed);
   return MT_OK;
 }
 
@@ -769,14 +749,12 @@ int mtgpu_scan_frames(mtgpu_ctx *c, const mt_mv *mv, const uint64_t *frame_off,
   DrainOnExit drain{st};
   if (n_records)
     HIP_TRY(hipMemcpyAsync(c->d_mv.p, mv + r_begin, (size_t)n_records * MT_MV_BYTES, hipMemcpyHostToDevice, st));
-  // offsets are rebased to the copied window on the device side by passing a shifted base
   HIP_TRY(hipMemcpyAsync(c->d_off.p, frame_off, sizeof(uint64_t) * ((size_t)n_frames + 1), hipMemcpyHostToDevice, st));
   if (has_sd) HIP_TRY(hipMemcpyAsync(c->d_sd.p, has_sd, n_frames, hipMemcpyHostToDevice, st));
-  // records of frame f live at d_mv + (frame_off[f] - r_begin) * 40: shift the base pointer
-  const unsigned char *base = static_cast<const unsigned char *>(c->d_mv.p) - (size_t)r_begin * MT_MV_BYTES;
-  rc = launch_scan_on(c, base, r_end, static_cast<const uint64_t *>(c->d_off.p),
+  // records of frame f live at d_mv + (frame_off[f] - r_begin) * 40: the work list is built with rebased offsets
+  rc = launch_scan_on(c, c->d_mv.p, r_end, static_cast<const uint64_t *>(c->d_off.p),
                       has_sd ? static_cast<const uint8_t *>(c->d_sd.p) : nullptr, n_frames,
-                      static_cast<uint8_t *>(c->d_flags.p), st);
+                      static_cast<uint8_t *>(c->d_flags.p), st, MT_MV_BYTES, 0, r_begin);
   if (rc != MT_OK) return rc;
   HIP_TRY(hipMemcpyAsync(flags, c->d_flags.p, n_frames, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));

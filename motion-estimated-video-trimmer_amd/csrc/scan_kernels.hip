@@ -467,34 +467,31 @@ struct NextStep {
   bool have;
 };
 
-// One work item (a frame, or a frame slice) by one workgroup.  `has_next`: the same workgroup scans item + 1
-// (the following frame) right after this one.
+// One work item (a frame of the work list, or a slice of one) by one workgroup.  `has_next`: the same workgroup scans
+// item + 1 (the next frame of the list) right after this one.  Returns false when the list has ended (every later
+// item is past its end too).
 template <int BLOCK, int UNROLL, int FB, int MODE, int VAR, int REC, bool SPILL>
-__device__ __forceinline__ void scan_item(
-    const unsigned char *__restrict__ mv, unsigned long long n_records,
-    const unsigned long long *__restrict__ frame_off, const unsigned char *__restrict__ has_sd,
+__device__ __forceinline__ bool scan_item(
+    const unsigned char *__restrict__ mv, const WorkItem *__restrict__ work,
     const unsigned int item, const ScanK &k, unsigned char *__restrict__ flags,
     unsigned int *spill_q, unsigned int *slice_ws, unsigned int *tickets, unsigned int *lds,
     NextStep<UNROLL> &ns, const bool has_next) {
   typedef typename RawOf<REC>::type Raw;
   const int tid = threadIdx.x;
-  // item -> frame, or (frame, slice): bands and slices are never both > 1
+  // item -> list entry, or (list entry, slice): bands and slices are never both > 1
   PT_DECL;
-  const unsigned int f = SPILL ? item : item / (unsigned int)k.slices;
-  const int slice = SPILL ? 0 : (int)(item - f * (unsigned int)k.slices);
+  const unsigned int wi = SPILL ? item : item / (unsigned int)k.slices;
+  const int slice = SPILL ? 0 : (int)(item - wi * (unsigned int)k.slices);
+  // the frame: one 32-byte entry of the work list (workgroup-uniform address: a scalar load).  Frames without side
+  // data (:219-221) never get here: plan_scatter_kernel has answered them.
+  const WorkItem me = work[wi];
+  const unsigned int f = me.f;
+  if (f == kNoFrame) return false;
   // A pre-issued step is consumed only by the frame it was loaded for: whatever early-out a frame takes
   // between here and its streaming loop, a step that was not consumed can never leak its votes into a LATER frame.
   if (ns.have && ns.frame != f) ns.have = false;
 
-  unsigned long long r0 = frame_off[f], r1 = frame_off[f + 1];
-  r1 = r1 < n_records ? r1 : n_records;
-  r0 = r0 < r1 ? r0 : r1;
-  const bool sd = has_sd ? (has_sd[f] != 0) : (r1 > r0);
-  if (!sd) {                                   // :219-221 — no side data: false
-    if (slice == 0 && tid == 0) store_flag(flags, f, 0, k.sys_flags);
-    ns.have = false;                           // (never set for such a frame today: a step is only pre-issued for frames with side data)
-    return;
-  }
+  unsigned long long r0 = me.r0, r1 = me.r1;
   const unsigned long long q0 = r0;            // the frame's spill queue: one slot per record
   if (!SPILL && k.slices > 1) {                // this workgroup's share of the frame's records
     const unsigned long long n = r1 - r0, per = (n + (unsigned long long)k.slices - 1ull) / (unsigned long long)k.slices;
@@ -668,11 +665,10 @@ __device__ __forceinline__ void scan_item(
       }
       if constexpr (REC == 8 && !SPILL) {
         if (has_next && k.slices == 1 && k.vec_need != 0u && trows > 0) {   // exactly when the next frame's phase 1 runs
-          // next frame: records [frame_off[f+1], frame_off[f+2]) — same clamps, same pair alignment as above
-          unsigned long long a = frame_off[f + 1], b = frame_off[f + 2];
-          b = b < n_records ? b : n_records;
-          a = a < b ? a : b;
-          const bool sdn = has_sd ? (has_sd[f + 1] != 0) : (b > a);
+          // next frame of the list (the list always ends in a kNoFrame entry): same pair alignment as above
+          const WorkItem nx = work[wi + 1u];
+          const unsigned long long a = nx.r0, b = nx.r1;
+          const bool sdn = nx.f != kNoFrame;
           const unsigned char *nb = mv + a * 8ull;
           const unsigned long long nn = b - a;
           const unsigned long long nhead = compact_head(nb, nn, k.align_lines);
@@ -683,7 +679,7 @@ __device__ __forceinline__ void scan_item(
             for (int u = 0; u < UNROLL; ++u)
               ns.d[u] = load_pair<VAR>(npb + ((unsigned long long)tid + (unsigned long long)u * BLOCK) * 16ull);
             ns.have = true;
-            ns.frame = f + 1u;
+            ns.frame = nx.f;
           }
         }
       }
@@ -767,7 +763,7 @@ __device__ __forceinline__ void scan_item(
       if (tid == 0)
         *ticket = __hip_atomic_fetch_add(&tickets[f], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __syncthreads();
-      if (*ticket != (unsigned int)(k.slices - 1)) { PT_ADD(3); PT_FLUSH(); return; }   // not the last: done
+      if (*ticket != (unsigned int)(k.slices - 1)) { PT_ADD(3); PT_FLUSH(); return true; }   // not the last: done
       if (tid == 0) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -879,152 +875,190 @@ __device__ __forceinline__ void scan_item(
 
   if (tid == 0) store_flag(flags, f, (*total >= k.clust_need) ? 1 : 0, k.sys_flags);
   PT_FLUSH();
+  return true;
 }
 
-// Grid: one workgroup per k.group consecutive work items.  Small frames (below ~128 KB: a few
+// Grid: one workgroup per k.group consecutive items of the work list.  Small frames (below ~128 KB: a few
 // microseconds of work) are grouped: the dispatcher starts ~19 workgroups per microsecond, which
 // keeps too few such workgroups alive per CU to overlap their zeroing and cluster tests; a
 // workgroup that scans a few frames in a row lives long enough (choose_group, mtgpu_api.hip).
+// The grid is sized for "every frame has side data"; the workgroups past the end of the list find a kNoFrame entry
+// and leave — all of them at the END of the grid, after the last workgroup with work, whatever the stream's key-frame
+// period is.
 template <int BLOCK, int UNROLL, int FB, int MODE, int VAR, int REC, bool SPILL>
 __global__ __launch_bounds__(BLOCK) void scan_frames_kernel(
-    const unsigned char *__restrict__ mv, unsigned long long n_records,
-    const unsigned long long *__restrict__ frame_off, const unsigned char *__restrict__ has_sd,
+    const unsigned char *__restrict__ mv, const WorkItem *__restrict__ work,
     unsigned int item0, unsigned int n_items, ScanK k, unsigned char *__restrict__ flags,
-    unsigned int *spill_q, unsigned int *slice_ws, unsigned int *tickets) {
+    unsigned int *spill_q, unsigned int *slice_ws, unsigned int *tickets, unsigned int *next_ticket) {
   extern __shared__ __attribute__((aligned(16))) unsigned int lds[];
-  unsigned int wg = blockIdx.x;
-  if (k.xcd_mix) {                             // only whole octets of this launch are permuted (a bijection inside each)
-    const unsigned int q = wg >> 3;
-    if (((q + 1u) << 3) <= gridDim.x) wg = (q << 3) | ((wg + ((q * 0x9E3779B1u) >> 29)) & 7u);
-  }
-  const unsigned int first = item0 + wg * (unsigned int)k.group;
   NextStep<UNROLL> ns;
   ns.have = false;
   ns.frame = 0u;
+  if constexpr (kExperiments) {
+    if (k.resident > 0) {
+      // A/B form (experiments build, MTGPU_RESIDENT = workgroups per CU): a fixed grid of workgroups pulls k.group
+      // items at a time with one agent-scope atomic; the next ticket is on its way while the current items are
+      // scanned.  The loop ends for every workgroup: tickets only grow, and the first one at or past n_items (or
+      // the first kNoFrame entry) is the last this workgroup takes.
+      unsigned int *slot = lds + (k.cnt_words + 2 * k.mask_rows * k.W + 4);     // one word past the kernel's own LDS use
+      unsigned int nextv = 0u;
+      if (threadIdx.x == 0) nextv = __hip_atomic_fetch_add(next_ticket, (unsigned int)k.group, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) *slot = nextv;
+        __syncthreads();
+        const unsigned int first = *slot;
+        if (first >= n_items) return;
+        if (threadIdx.x == 0) nextv = __hip_atomic_fetch_add(next_ticket, (unsigned int)k.group, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int g = 0; g < k.group; ++g) {
+          const unsigned int item = first + (unsigned int)g;
+          if (item >= n_items) return;
+          const bool has_next = (g + 1 < k.group) && (item + 1u < n_items) && k.prefetch;
+          if (!scan_item<BLOCK, UNROLL, FB, MODE, VAR, REC, SPILL>(mv, work, item, k, flags, spill_q, slice_ws, tickets, lds, ns, has_next))
+            return;
+        }
+      }
+    }
+  }
+  const unsigned int first = item0 + blockIdx.x * (unsigned int)k.group;
   for (int g = 0; g < k.group; ++g) {
     const unsigned int item = first + (unsigned int)g;
     if (item >= n_items) break;
     // (no barrier between items: every LDS read of an item precedes its last barrier, and the
     //  next item's writes start with its own zeroing)
     const bool has_next = (g + 1 < k.group) && (item + 1u < n_items) && k.prefetch;
-    scan_item<BLOCK, UNROLL, FB, MODE, VAR, REC, SPILL>(mv, n_records, frame_off, has_sd, item, k, flags, spill_q,
-                                                         slice_ws, tickets, lds, ns, has_next);
+    if (!scan_item<BLOCK, UNROLL, FB, MODE, VAR, REC, SPILL>(mv, work, item, k, flags, spill_q, slice_ws, tickets, lds, ns, has_next))
+      break;
   }
 }
 
-// Calibration only: a kernel that ONLY reads, so that bench.py can state what a pure read reaches on the very buffer
-// the scan streams ("measured read ceiling", beside the 8 TB/s spec peak).  One workgroup of 512 threads per
-// contiguous chunk, nt loads, four in flight per lane, folded into a value that is (almost) never stored.  Two load
-// shapes — a ceiling has to be at least as good as what it bounds, so bench.py sweeps both (and a few chunk sizes)
-// and reports the best:
-//   SHAPE 0  16 contiguous bytes per lane (every byte of the buffer crosses into the CU)
-//   SHAPE 1  the scan's own: bytes 4..15 of every 40-byte record, one record per lane (every LINE is fetched, 12 of
-//            40 bytes reach the registers)
-//   SHAPE 2  SHAPE 1 plus the arithmetic the scan spends on a record that does not vote (decode, |d|^2, compare, one
-//            ballot per wave instruction)
-//   SHAPE 3  SHAPE 2 inside the scan's frame: the workgroup first zeroes an LDS tile of the plan's size and walks it
-//            once at the end — with a chunk of one frame this is the scan kernel with the votes taken out
-template <int SHAPE>
-__global__ __launch_bounds__(512) void read_ceiling_kernel(const unsigned char *__restrict__ p, unsigned long long bytes,
-                                                           unsigned long long chunk, unsigned long long thr,
-                                                           unsigned int lds_words, unsigned int skip,
-                                                           unsigned int *__restrict__ sink) {
-  // `skip` > 1: every skip-th workgroup has nothing to do and leaves at once — the I-frames of a stream (frames
-  // without records), which stagger the workgroups of a launch against each other
-  const unsigned int bi = blockIdx.x;
-  unsigned long long cb = bi;
-  if (skip > 1u) {
-    if (bi % skip == 0u) return;
-    cb = bi - (bi / skip + 1u);
+// ------------------------------------------------------------------ the work list (plan_frames)
+//
+// Ahead of every scan, over the batch's offsets only (8 bytes per frame, never the records): every frame is ranked
+// among the frames WITH side data before it (ballot + popcount inside a wave, 16 wave totals through LDS, the blocks
+// before this one added up) and written to
+//     work[rank]                              = {r0, r1, f}                 a frame with side data
+//     work[n_frames - 1 - #empty before f]    = kNoFrame, flags[f] = 0      one without (:219-221)
+// so the list is: every frame with side data in stream order, then kNoFrame up to n_frames (+ one more: the entry the
+// last frame's "next frame" read finds).  Deterministic: no atomics on global memory, no block waits for another.
+// How a block learns the count of the blocks before it:
+//   up to kPlanFused blocks (32 768 frames)   ONE kernel: every block counts the frames before its own again — at most
+//                                             31 coalesced 8-byte loads per lane, cheaper than a second launch
+//   more                                      plan_count_kernel writes one count per block, plan_scatter_kernel adds up
+//                                             at most 1024 of them
+// has_sd == NULL: a frame has side data iff it has records; has_sd[f] != 0 with no records is a frame whose side data
+// is empty: it reaches the scan, which then runs the cluster test on an all-zero grid (vectors_needed == 0 matters).
+__device__ __forceinline__ bool plan_frame(const unsigned long long *__restrict__ frame_off, const unsigned char *__restrict__ has_sd,
+                                           unsigned long long n_records, unsigned long long f, unsigned long long &r0,
+                                           unsigned long long &r1) {
+  r0 = frame_off[f];
+  r1 = frame_off[f + 1];
+  r1 = r1 < n_records ? r1 : n_records;
+  r0 = r0 < r1 ? r0 : r1;
+  return has_sd ? (has_sd[f] != 0) : (r1 > r0);
+}
+
+__global__ __launch_bounds__(kPlanBlock) void plan_count_kernel(
+    const unsigned long long *__restrict__ frame_off, const unsigned char *__restrict__ has_sd, unsigned long long n_records,
+    unsigned int n_frames, unsigned int per, unsigned int *__restrict__ blk_cnt) {
+  __shared__ unsigned int total;
+  if (threadIdx.x == 0) total = 0u;
+  __syncthreads();
+  unsigned int mine = 0u;
+  for (unsigned int i = 0; i < per; ++i) {
+    const unsigned long long f = ((unsigned long long)blockIdx.x * per + i) * kPlanBlock + threadIdx.x;
+    unsigned long long r0, r1;
+    const bool sd = f < n_frames && plan_frame(frame_off, has_sd, n_records, f, r0, r1);
+    mine += (unsigned int)__popcll(__ballot(sd));        // every lane of the wave holds the wave's count
   }
-  const unsigned long long c0 = min(bytes, cb * chunk);
-  const unsigned long long c1 = min(bytes, c0 + chunk);
-  constexpr unsigned long long UNIT = SHAPE == 0 ? 16ull : 40ull;      // (SHAPE 2 = SHAPE 1 plus the scan's per-record arithmetic)
-  extern __shared__ __attribute__((aligned(16))) unsigned int tile[];
-  if constexpr (SHAPE == 3) {                                           // the scan's phase 0: zero the workgroup's LDS tile
-    for (unsigned int q = threadIdx.x; q < lds_words / 4u; q += 512u) reinterpret_cast<u32x4 *>(tile)[q] = (u32x4){0u, 0u, 0u, 0u};
-    __syncthreads();
-  }
-  const unsigned char *base = p + c0;
-  const unsigned long long n = (c1 - c0) / UNIT;
-  unsigned long long i = threadIdx.x;
-  unsigned int acc = 0u;
-  for (; i + 3ull * 512ull < n; i += 4ull * 512ull) {
-    if constexpr (SHAPE == 0) {
-      u32x4 v[4];
+  if ((threadIdx.x & 63u) == 0u && mine != 0u) atomicAdd(&total, mine);
+  __syncthreads();
+  if (threadIdx.x == 0) blk_cnt[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(kPlanBlock) void plan_scatter_kernel(
+    const unsigned long long *__restrict__ frame_off, const unsigned char *__restrict__ has_sd, unsigned long long n_records,
+    unsigned long long rebase, unsigned int n_frames, unsigned int per,
+    const unsigned int *__restrict__ blk_cnt, WorkItem *__restrict__ work, unsigned char *__restrict__ flags, int sys_flags,
+    unsigned int *next_ticket) {
+  constexpr unsigned int WAVES = kPlanBlock / 64u;
+  __shared__ unsigned int before;                // frames with side data in the blocks before this one
+  __shared__ unsigned int wave_cnt[WAVES];
+  const unsigned int tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  if (tid == 0u) before = 0u;
+  __syncthreads();
+  if (blockIdx.x != 0u) {
+    unsigned int mine = 0u;
+    if (blk_cnt) {
+      for (unsigned int j = tid; j < blockIdx.x; j += kPlanBlock) mine += blk_cnt[j];
+      if (mine) atomicAdd(&before, mine);
+    } else {                                     // fused form (per == 1): count the frames of the blocks before this one
+      // (blockIdx.x whole blocks of kPlanBlock frames: the trip count is uniform; four blocks' loads in flight per step)
+      for (unsigned int j = 0; j < blockIdx.x; j += 4u) {
+        bool sd[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_a16 *>(base + (i + (unsigned long long)u * 512ull) * 16ull));
-#pragma unroll
-      for (int u = 0; u < 4; ++u) acc ^= v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
-    } else {
-      u32x3 v[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = load_fields<0>(base + (i + (unsigned long long)u * 512ull) * 40ull);
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if constexpr (SHAPE >= 2) {
-          // ... and what the scan does with a record that does not vote: decode, |d|^2, compare, one ballot
-          const MvFields m = decode(v[u]);
-          const unsigned int dx = (unsigned int)(m.dst_x - m.src_x), dy = (unsigned int)(m.dst_y - m.src_y);
-          const unsigned long long mag = (unsigned long long)(dx * dx) + (unsigned long long)(dy * dy);
-          acc += (unsigned int)__popcll(__ballot(mag >= thr));       // thr: a kernel argument no record reaches
-        } else {
-          acc ^= v[u].x ^ v[u].y ^ v[u].z;
+        for (unsigned int u = 0; u < 4u; ++u) {
+          unsigned long long r0, r1;
+          sd[u] = (j + u < blockIdx.x) && plan_frame(frame_off, has_sd, n_records, (unsigned long long)(j + u) * kPlanBlock + tid, r0, r1);
         }
-      }
-    }
-  }
-  {
-    // the rest (fewer than one step): every load issued before the first one is used, as in the scan's tail — one
-    // memory round trip, not up to four in a row at the end of every workgroup's life
-    bool ok[4];
-    u32x4 v0[4];
-    u32x3 v1[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const unsigned long long q = i + (unsigned long long)u * 512ull;
-      ok[u] = q < n;
-      v0[u] = (u32x4){0u, 0u, 0u, 0u};
-      v1[u] = (u32x3){0u, 0u, 0u};
-      if (ok[u]) {
-        if constexpr (SHAPE == 0) v0[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_a16 *>(base + q * 16ull));
-        else v1[u] = load_fields<0>(base + q * 40ull);
+        for (unsigned int u = 0; u < 4u; ++u) mine += (unsigned int)__popcll(__ballot(sd[u]));
       }
+      if (lane == 0u && mine) atomicAdd(&before, mine);                     // every lane holds its wave's count
     }
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (ok[u]) acc ^= v0[u].x ^ v0[u].y ^ v0[u].z ^ v0[u].w ^ v1[u].x ^ v1[u].y ^ v1[u].z;
-  }
-  if constexpr (SHAPE == 3) {                                           // the scan's phase 2, in outline: one pass over the tile
     __syncthreads();
-    for (unsigned int q = threadIdx.x; q < lds_words; q += 512u) acc += tile[q];
   }
-  if (acc == 0x9E3779B9u) *sink = acc;   // keeps the loads alive
+  unsigned int running = before;                 // frames with side data before the frames of this iteration
+  for (unsigned int i = 0; i < per; ++i) {
+    const unsigned long long f = ((unsigned long long)blockIdx.x * per + i) * kPlanBlock + tid;
+    unsigned long long r0 = 0ull, r1 = 0ull;
+    const bool valid = f < n_frames;
+    const bool sd = valid && plan_frame(frame_off, has_sd, n_records, f, r0, r1);
+    const unsigned long long b = __ballot(sd);
+    if (lane == 0u) wave_cnt[wave] = (unsigned int)__popcll(b);
+    __syncthreads();
+    unsigned int below = 0u, all = 0u;           // waves before this one; the whole block
+#pragma unroll
+    for (unsigned int w = 0; w < WAVES; ++w) {
+      const unsigned int c = wave_cnt[w];
+      below += w < wave ? c : 0u;
+      all += c;
+    }
+    const unsigned int rank = running + below + (unsigned int)__popcll(b & ((1ull << lane) - 1ull));   // side-data frames before f
+    if (valid) {
+      WorkItem it;
+      it.pad[0] = it.pad[1] = it.pad[2] = 0u;
+      if (sd) {
+        it.r0 = r0 > rebase ? r0 - rebase : 0ull; it.r1 = r1 > rebase ? r1 - rebase : 0ull; it.f = (unsigned int)f;
+        work[rank] = it;
+      } else {
+        it.r0 = it.r1 = 0ull; it.f = kNoFrame;
+        work[(unsigned long long)(n_frames - 1u) - (f - rank)] = it;      // f - rank frames without side data before f
+        store_flag(flags, (unsigned int)f, 0, sys_flags);                 // :219-221 — no side data: false
+      }
+    }
+    running += all;
+    __syncthreads();                             // wave_cnt is rewritten by the next iteration
+  }
+  if (blockIdx.x == 0 && tid == 0) {
+    WorkItem it;
+    it.r0 = it.r1 = 0ull; it.f = kNoFrame; it.pad[0] = it.pad[1] = it.pad[2] = 0u;
+    work[n_frames] = it;                         // what the last frame's "next frame" read finds
+    *next_ticket = 0u;                           // (resident form, experiments build)
+  }
 }
 
-hipError_t launch_read_ceiling(const void *p, unsigned long long bytes, int shape, unsigned long long chunk,
-                               unsigned int lds_bytes, unsigned int skip, unsigned int *sink, hipStream_t stream) {
-  if (chunk == 0) chunk = 1280ull * 1024ull;
-  if (shape == 0) chunk &= ~15ull;           // chunks of whole 16-byte units (the buffer itself is 16-byte aligned)
-  else chunk -= chunk % 40ull;               // ... of whole records
-  if (chunk == 0 || bytes < chunk) return hipSuccess;
-  unsigned long long blocks = (bytes + chunk - 1) / chunk;
-  if (skip > 1u) blocks = blocks + blocks / (skip - 1u) + 2u;     // room for the workgroups that leave at once
-  if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
-  if (shape == 0)
-    hipLaunchKernelGGL(read_ceiling_kernel<0>, dim3((unsigned int)blocks), dim3(512), 0, stream,
-                       static_cast<const unsigned char *>(p), bytes, chunk, 1ull << 40, 0u, skip, sink);
-  else if (shape == 3) {
-    // (<= 64 KB of LDS: the default limit of a kernel that never asked for more)
-    const unsigned int lb = std::min(lds_bytes, 64u * 1024u) & ~15u;
-    hipLaunchKernelGGL(read_ceiling_kernel<3>, dim3((unsigned int)blocks), dim3(512), lb, stream,
-                       static_cast<const unsigned char *>(p), bytes, chunk, 1ull << 40, lb / 4u, skip, sink);
-  } else if (shape == 2)
-    hipLaunchKernelGGL(read_ceiling_kernel<2>, dim3((unsigned int)blocks), dim3(512), 0, stream,
-                       static_cast<const unsigned char *>(p), bytes, chunk, 1ull << 40, 0u, skip, sink);
-  else
-    hipLaunchKernelGGL(read_ceiling_kernel<1>, dim3((unsigned int)blocks), dim3(512), 0, stream,
-                       static_cast<const unsigned char *>(p), bytes, chunk, 1ull << 40, 0u, skip, sink);
+static hipError_t launch_plan(const ScanLaunch &L, WorkItem *work, unsigned int *blk_cnt, unsigned int *next_ticket) {
+  const unsigned int per = plan_per(L.n_frames), blocks = plan_blocks(L.n_frames);
+  const bool fused = blocks <= kPlanFused;       // (then per == 1)
+  if (!fused) {
+    hipLaunchKernelGGL(plan_count_kernel, dim3(blocks), dim3(kPlanBlock), 0, L.stream, L.frame_off, L.has_sd, L.n_records,
+                       L.n_frames, per, blk_cnt);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(plan_scatter_kernel, dim3(blocks), dim3(kPlanBlock), 0, L.stream, L.frame_off, L.has_sd, L.n_records,
+                     L.rebase, L.n_frames, per, fused ? nullptr : blk_cnt, work, L.flags, L.k.sys_flags, next_ticket);
   return hipGetLastError();
 }
 
@@ -1065,14 +1099,22 @@ static hipError_t launch_one(const ScanLaunch &L) {
   }
   const unsigned long long items = (unsigned long long)L.n_frames * (unsigned long long)(SPILL ? 1 : L.k.slices);
   const unsigned long long group = (unsigned long long)(L.k.group > 0 ? L.k.group : 1);
+  WorkItem *work = static_cast<WorkItem *>(L.plan_ws);
+  unsigned int *next_ticket = reinterpret_cast<unsigned int *>(work + (size_t)L.n_frames + 1u) + plan_blocks(L.n_frames);
+  if (kExperiments && L.k.resident > 0) {
+    const unsigned long long want = (unsigned long long)(L.cu_count > 0 ? L.cu_count : 256) * (unsigned long long)L.k.resident;
+    const unsigned long long wgs = (items + group - 1) / group;
+    hipLaunchKernelGGL(kern, dim3((unsigned int)(wgs < want ? wgs : want)), dim3(BLOCK), L.lds_bytes + 16, L.stream, L.mv, work,
+                       0u, (unsigned int)items, L.k, L.flags, L.spill_q, L.slice_ws, L.tickets, next_ticket);
+    return hipGetLastError();
+  }
   const unsigned long long chunk = L.item_chunk ? L.item_chunk : (1ull << 30);   // workgroups per launch: grid.x stays < 2^31
   for (unsigned long long i0 = 0; i0 < items; i0 += chunk * group) {
     const unsigned long long left = items - i0;
     const unsigned long long wgs = (left + group - 1) / group;
     const unsigned int n = (unsigned int)(wgs < chunk ? wgs : chunk);
-    hipLaunchKernelGGL(kern, dim3(n), dim3(BLOCK), L.lds_bytes, L.stream, L.mv, L.n_records,
-                       L.frame_off, L.has_sd, (unsigned int)i0, (unsigned int)items, L.k, L.flags, L.spill_q,
-                       L.slice_ws, L.tickets);
+    hipLaunchKernelGGL(kern, dim3(n), dim3(BLOCK), L.lds_bytes, L.stream, L.mv, work, (unsigned int)i0,
+                       (unsigned int)items, L.k, L.flags, L.spill_q, L.slice_ws, L.tickets, next_ticket);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
@@ -1146,6 +1188,13 @@ hipError_t launch_scan(const ScanLaunch &L) {
   if (L.k.slices > 1) {
     if (!L.slice_ws || !L.tickets) return hipErrorInvalidValue;
     e = hipMemsetAsync(L.tickets, 0, sizeof(unsigned int) * (size_t)L.n_frames, L.stream);
+    if (e != hipSuccess) return e;
+  }
+  if (!L.plan_ws || ((uintptr_t)L.plan_ws & 31u) != 0u || !L.frame_off || L.rebase > L.n_records) return hipErrorInvalidValue;
+  {
+    WorkItem *work = static_cast<WorkItem *>(L.plan_ws);
+    unsigned int *blk_cnt = reinterpret_cast<unsigned int *>(work + (size_t)L.n_frames + 1u);
+    e = launch_plan(L, work, blk_cnt, blk_cnt + plan_blocks(L.n_frames));
     if (e != hipSuccess) return e;
   }
   switch (L.block) {

@@ -235,11 +235,6 @@ class MotionScanner:
         """Workgroups per frame: 0 = automatic (default), or 1 / 2 / 4 / 8.  Never changes results."""
         check(self._lib.mtgpu_set_slices(self._ctx, int(slices)))
 
-    def set_frame_order(self, mixed: bool):
-        """Frames in order (default) or rotated inside octets of workgroups (mtgpu_set_frame_order): for streams whose
-        key-frame period shares a factor with 8.  Never changes results."""
-        check(self._lib.mtgpu_set_frame_order(self._ctx, 1 if mixed else 0))
-
     def stats(self) -> dict:
         """What the context holds on the device (mtgpu_get_stats): staging of the host-pointer entry points,
         the scratch pool's reserved bytes now and at its high-water mark."""

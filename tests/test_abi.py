@@ -126,9 +126,9 @@ def test_pack_records_known_answer():
 
 
 def test_every_environment_knob_is_in_the_headers_table():
-    """include/mtgpu.h "Environment": one table for every MTGPU_* variable the library and the C++ host layer read,
-    in the class in which the code reads it — supported knobs through env_int() / getenv (every build), experiment
-    knobs through exp_int() (csrc/knobs.h: constants unless built with -DMTGPU_EXPERIMENTS)."""
+    """Every MTGPU_* variable the library and the C++ host layer read is listed in the class in which the code reads
+    it: supported knobs (env_int() / getenv, every build) in include/mtgpu.h "Environment"; experiment knobs (exp_int():
+    constants unless built with -DMTGPU_EXPERIMENTS) in csrc/knobs.h only — the product header does not carry them."""
     import re
     csrc = os.path.join(os.path.dirname(m.LIB_PATH), "csrc")
     files = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".cpp", ".h"))]
@@ -140,8 +140,9 @@ def test_every_environment_knob_is_in_the_headers_table():
         supported |= set(re.findall(r'(?:env_int|env_i|getenv)\("(MTGPU_[A-Z0-9_]+)"', text))
     header = open(os.path.join(ROOT, "include", "mtgpu.h")).read()
     table = header[header.index(" * Environment (read once"):header.index("#ifndef MTGPU_H")]
-    exp_part = table[table.index("experiments   "):]
-    sup_part = table[:table.index("experiments   ")]
+    knobs = open(os.path.join(csrc, "knobs.h")).read()
+    exp_part = knobs[knobs.index("//    experiments   "):knobs.index("#pragma once")]
+    sup_part = table
     listed = lambda part: set(re.findall(r"MTGPU_[A-Z0-9_]+", part.replace("MTGPU_INJECT_SUBMIT_FAIL / _GROW_FAIL / _COLLECT_FAIL",
                                                                            "MTGPU_INJECT_SUBMIT_FAIL MTGPU_INJECT_GROW_FAIL MTGPU_INJECT_COLLECT_FAIL")))
     assert experiments and supported and not (experiments & supported - {"MTGPU_FORCE_BLOCK"})

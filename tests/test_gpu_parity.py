@@ -59,17 +59,30 @@ def test_scan_1080p_stream(gpu_scanner_factory, cfg, sub):
     assert np.array_equal(got2, want)
 
 
-@pytest.mark.parametrize("force_fb", [None, 32])
-def test_scan_4k_stream(gpu_scanner_factory, force_fb):
-    spec = synth.spec_4k(seed=5)
+@pytest.mark.parametrize("force_fb", [None, 2, 32])
+@pytest.mark.parametrize("cfg,sub", [("code_defaults", 2), ("shipped_env", 2), ("code_defaults", 1), ("shipped_env", 1)])
+def test_scan_4k_stream(gpu_scanner_factory, force_fb, cfg, sub):
+    """BASELINE config 3 (240x135) with BOTH parameter sets SURVEY 8(d) names — code defaults (T 16, VECTORS_NEEDED 2)
+    and the shipped env (T 4, VECTORS_NEEDED 4: config/motion_trim.env:36, 75) — at four records per 16-px cell and at
+    one (VECTORS_NEEDED 1 then: one record per cell never collects two votes), on the 124 KB tile of 32-bit counters
+    the planner picks, on the forced packed form (2-bit fields where they can count VECTORS_NEEDED, the planner's
+    narrowest packed form otherwise) and on forced 32-bit counters."""
+    kw = dict(m.config.CODE_DEFAULTS if cfg == "code_defaults" else m.config.SHIPPED_ENV)
+    if sub == 1:
+        kw["vectors_needed"] = 1
+    spec = synth.spec_4k(seed=5 + sub, sub=sub)
     spec.events = synth.scripted_events(spec, 16)
     spec.events.append(synth.Event(3, 9, 100, 60, 4, 3, 9, -5))
     mv, off, pts, sd = synth.gen_stream(spec, 16)
-    p = ob.params_from_config(3840, 2160)
+    p = ob.params_from_config(3840, 2160, **kw)
     assert (p.grid_w, p.grid_h, p.vertical_margin) == (240, 135, 6)
     s = gpu_scanner_factory(p, force_fb=force_fb)
+    if force_fb is None:
+        assert s.plan["counter_bits"] == 32 and s.plan["bands"] == 1 and s.plan["lds_bytes"] > 120 * 1024
+    elif force_fb == 2:
+        assert s.plan["counter_bits"] == (2 if p.vectors_needed <= 2 else 4)
     want = assert_scan_parity(s, p, mv, off, sd)
-    assert want.sum() >= 6
+    assert 6 <= want.sum() < len(want)
 
 
 @pytest.mark.parametrize("force_fb", [None, 2, 8, 108, 32])
@@ -384,32 +397,73 @@ def test_scan_device_resident_matches_host_path(gpu_scanner_factory):
     assert np.array_equal(got2.cpu().numpy(), want)
 
 
-def test_scan_batch_properties_full_size(gpu_scanner_factory):
+@pytest.mark.parametrize("grid,cfg", [("1080p", "code_defaults"), ("4k", "code_defaults"), ("4k", "shipped_env")])
+def test_scan_batch_properties_full_size(gpu_scanner_factory, grid, cfg):
     """Size-independent properties at bench scale (the oracle is too slow to recheck all of
     it): the flags of a tiled batch are the tile's flags repeated, and permuting frames
-    permutes flags."""
+    permutes flags.  1080p and 4K (config 3, both parameter sets)."""
     import torch
-    spec = synth.spec_1080p(seed=21)
+    kw = dict(m.config.CODE_DEFAULTS if cfg == "code_defaults" else m.config.SHIPPED_ENV)
+    if grid == "1080p":
+        spec, (W, H), reps = synth.spec_1080p(seed=21), (1920, 1080), 128      # 4096 frames, 5.3 GB of records:
+    else:                                                                        # offsets cross 2^32 bytes
+        spec, (W, H), reps = synth.spec_4k(seed=22), (3840, 2160), 32          # 1024 4K frames, 5.3 GB
     spec.events = synth.scripted_events(spec, 32)
     mv, off, pts, sd = synth.gen_stream(spec, 32)
-    p = ob.params_from_config(1920, 1080)
+    p = ob.params_from_config(W, H, **kw)
     s = gpu_scanner_factory(p)
     want = ob.scan_frames(p, mv, off, None)
-    reps = 128                                  # 4096 frames, 5.3 GB of records: offsets cross 2^32 bytes
+    assert 0 < want.sum() < 32
     d_tile = torch.from_numpy(mv.view(np.uint8).copy()).cuda()
     d_mv = d_tile.repeat(reps)
     counts = np.diff(off.astype(np.int64))
     off_big = np.concatenate([[0], np.cumsum(np.tile(counts, reps))]).astype(np.int64)
     got = s.check_frames_device(d_mv, torch.from_numpy(off_big).cuda()).cpu().numpy()
     assert np.array_equal(got, np.tile(want, reps))
-    # reversed frame order over the same record array: offsets select frames back to front
-    starts = off_big[:-1][::-1].copy()
-    # a reversed batch needs its own packed array; build it on the host for the tile only
+    # reversed frame order: a reversed batch needs its own packed array; built on the host for the tile only
     order = np.arange(32)[::-1]
     frames = [mv[int(off[i]):int(off[i + 1])] for i in order]
     b = m.FrameBatch.from_frames(frames)
     assert np.array_equal(s.check_frames(m.FrameBatch(b.mv, b.frame_off)), want[order])
-    del starts
+
+
+@pytest.mark.parametrize("n_frames", [1, 63, 1024, 1025, 5000, 32768, 32769, 70001])
+def test_work_list_every_plan_size(gpu_scanner_factory, n_frames):
+    """The planning kernels at every size class: one block (<= 1024 frames), the fused form (<= 32 blocks: every block
+    counts the frames before it again), the two-kernel form beyond — tiny frames (0..3 records, a third of them without
+    side data, some with EMPTY side data), so that the oracle checks every one of up to 70 001 flags.  VECTORS_NEEDED 0
+    makes the three kinds of frames differ: no side data -> false, empty side data -> true (every cell is active),
+    records -> true."""
+    import torch
+    rng = np.random.RandomState(n_frames)
+    kind = rng.randint(0, 6, size=n_frames)                   # 0, 1: no side data; 2: empty side data; 3..5: 1..3 records
+    counts = np.where(kind >= 3, kind - 2, 0).astype(np.int64)
+    has_sd = (kind >= 2).astype(np.uint8)
+    off = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
+    n = int(off[-1])
+    mv = np.zeros(max(n, 1), dtype=m.MV_DTYPE)[:n]
+    mv["dst_x"], mv["dst_y"] = rng.randint(0, 1920, size=n), rng.randint(0, 1080, size=n)
+    mv["src_x"], mv["src_y"] = mv["dst_x"] - rng.choice([0, 3], size=n), mv["dst_y"]      # |d|^2 <= 9: below the threshold
+    three = off[:-1][kind == 5].astype(np.int64)              # frames with three records: two of them moving, side by side
+    for q, gx in ((0, 50), (1, 51)):
+        mv["dst_x"][three + q], mv["dst_y"][three + q], mv["src_x"][three + q], mv["src_y"][three + q] = gx * 16 + 8, 488, gx * 16, 488
+    for vn, cn in ((0, 1), (1, 1)):
+        p = ob.params_from_config(1920, 1080, vectors_needed=vn, clusters_needed=cn)
+        s = gpu_scanner_factory(p)
+        want = ob.scan_frames(p, mv, off, has_sd, nthreads=8)
+        got = s.check_frames(m.FrameBatch(mv, off, None, has_sd))
+        bad = np.flatnonzero(want != got)
+        assert bad.size == 0, (vn, bad[:8], want[bad[:8]], got[bad[:8]], kind[bad[:8]])
+        if vn == 0:
+            assert np.array_equal(want, has_sd)              # side data (even empty) -> every cell active -> true
+        else:
+            assert np.array_equal(want, (kind == 5).astype(np.uint8))
+        # device entry point, has_sd == NULL (side data iff records), poisoned flags: every byte is written
+        d_flags = torch.full((n_frames,), 9, dtype=torch.uint8, device="cuda")
+        d_mv = torch.from_numpy(mv.view(np.uint8).copy()).cuda() if n else torch.zeros(40, dtype=torch.uint8, device="cuda")
+        s.check_frames_device(d_mv[: n * 40], torch.from_numpy(off.astype(np.int64)).cuda(), None, d_flags)
+        want2 = ob.scan_frames(p, mv, off, None, nthreads=8)
+        assert np.array_equal(d_flags.cpu().numpy(), want2), vn
 
 
 # ------------------------------------------------------------------ merge
@@ -1569,12 +1623,13 @@ def test_device_entry_points_with_flags_in_pinned_host_memory(gpu_scanner_factor
 
 
 @pytest.mark.parametrize("slices,group,chunk", [(0, "", ""), (2, "", ""), (0, "3", ""), (0, "", "5"), (0, "2", "7")])
-def test_frame_order_never_changes_results(gpu_scanner_factory, monkeypatch, slices, group, chunk):
-    """mtgpu_set_frame_order(ctx, 1): the 8 work items of every octet of workgroups are taken in an order rotated by a
-    hash of the octet's index (empty frames with a period of 8, 16, 32 ... would otherwise leave whole XCDs idle).
-    A permutation of who scans what: every flag as before — frames with and without records at periods 8 and 30, a batch
-    that is not a multiple of 8, frame slices, several frames per workgroup, launches cut into chunks of 5 and 7
-    workgroups (only whole octets of a launch are permuted), 40-byte and compact records."""
+@pytest.mark.parametrize("period", [2, 8, 30])
+def test_work_list_skips_frames_without_side_data(gpu_scanner_factory, monkeypatch, slices, group, chunk, period):
+    """The work list (plan_count_kernel / plan_scatter_kernel): frames WITHOUT side data are answered by the planning
+    kernels (false, src/motion_scanner.cpp:219-221) and never get a workgroup; frames with side data — also with EMPTY
+    side data — keep their stream order in the list.  Key frames every 2 / 8 / 30 frames (period 8 used to leave one XCD
+    without work), a batch that is not a multiple of 8, frame slices, several frames per workgroup, launches cut into
+    chunks of 5 and 7 workgroups, 40-byte and compact records, has_sd given and has_sd == NULL."""
     import torch
     for k_, v_ in (("MTGPU_GROUP", group), ("MTGPU_ITEM_CHUNK", chunk)):
         if v_:
@@ -1584,11 +1639,11 @@ def test_frame_order_never_changes_results(gpu_scanner_factory, monkeypatch, sli
     for k_ in ("MTGPU_GROUP", "MTGPU_ITEM_CHUNK"):
         monkeypatch.delenv(k_, raising=False)
     s.set_slices(slices)
-    rng = np.random.RandomState(11)
+    rng = np.random.RandomState(11 + period)
     frames = []
     for f in range(203):                                    # 203 = 25 octets + 3
-        if f % 8 == 0 or f % 30 == 0:
-            frames.append(None if f % 16 == 0 else np.zeros(0, dtype=m.MV_DTYPE))
+        if f % period == 0:
+            frames.append(None if f % (2 * period) == 0 else np.zeros(0, dtype=m.MV_DTYPE))
             continue
         n = int(rng.choice([1, 40, 700, 3000]))
         mv = np.zeros(n, dtype=m.MV_DTYPE)
@@ -1601,12 +1656,16 @@ def test_frame_order_never_changes_results(gpu_scanner_factory, monkeypatch, sli
         frames.append(mv)
     b = m.FrameBatch.from_frames(frames)
     want = ob.scan_frames(p, b.mv, b.frame_off, b.has_sd)
-    assert 20 < want.sum() < 150
+    assert 10 < want.sum() < 150
     rec8 = torch.from_numpy(m.pack_records(b.mv).view(np.uint8).copy()).cuda()
     d_off = torch.from_numpy(b.frame_off.astype(np.int64)).cuda()
     d_sd = torch.from_numpy(b.has_sd.astype(np.uint8)).cuda()
-    for mixed in (True, False, True):
-        s.set_frame_order(mixed)
-        assert np.array_equal(s.check_frames(b), want), mixed
-        assert np.array_equal(s.check_frames_device_compact(rec8, d_off, d_sd).cpu().numpy(), want), (mixed, "compact")
-    s.set_frame_order(False)
+    for _ in range(2):                                      # twice: the scratch of the first launch is reused
+        assert np.array_equal(s.check_frames(b), want)
+        assert np.array_equal(s.check_frames_device_compact(rec8, d_off, d_sd).cpu().numpy(), want), "compact"
+    # has_sd == NULL: side data iff records (with vectors_needed >= 1 a frame with empty side data is false either way)
+    assert np.array_equal(s.check_frames_device_compact(rec8, d_off, None).cpu().numpy(), want), "compact, has_sd NULL"
+    # every flag is WRITTEN, also the ones the planning kernels answer: start from a poisoned buffer
+    d_flags = torch.full((203,), 7, dtype=torch.uint8, device="cuda")
+    s.check_frames_device_compact(rec8, d_off, d_sd, d_flags)
+    assert np.array_equal(d_flags.cpu().numpy(), want)

@@ -47,7 +47,6 @@ def test_soak_random_parity(gpu_scanner_factory):
                 os.environ.pop(k_, None)
         tail = draw_tail(rng, it, head)
         s.set_slices(tail["slices"])
-        s.set_frame_order(it % 4 == 1)                  # (from the iteration count: the recorded random stream stays as it was)
         n_frames, mv, off, sd = tail["n_frames"], tail["mv"], tail["off"], tail["sd"]
         want = ob.scan_frames(p, mv, off, sd, nthreads=8)
         for _ in range(2):                              # twice: warm caches, reused workspaces
