@@ -42,6 +42,8 @@ HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; ~6
 # Every leg scans about 21 GB per launch, like the headline (a launch's ramp and tail are then the same small share
 # of every leg; rounds 1-2 used 5 GB for the 16-px grids).
 OTHER_WORKLOADS = [("4k_dense8x8", "code_defaults", 4096, 20),
+                   # SURVEY.md 8(d) config 3 names both parameter sets: the shipped env (T 4, VECTORS_NEEDED 4)
+                   ("4k_dense8x8", "shipped_env", 4096, 20),
                    ("4k_fine", "code_defaults", 1024, 12),
                    # shipped env (VECTORS_NEEDED 4) on the fine grid needs >= 4 records per 4x4 block somewhere to
                    # ever say yes: the dense4 density (4 per block inside moving regions, ragged frames)
@@ -72,6 +74,11 @@ def parse(argv=None):
     ap.add_argument("--no-merge", action="store_true", help="time the scan kernel alone")
     ap.add_argument("--no-others", action="store_true", help="skip the other_workloads leg")
     ap.add_argument("--no-host", action="store_true", help="skip the host-fed (PCIe-inclusive) leg")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="do not measure roofline.traffic with rocprofv3 child runs (N = 1 only; the committed figure is replayed)")
+    ap.add_argument("--pmc-child", action="store_true",
+                    help="internal: the process rocprofv3 profiles for roofline.traffic — builds the workload, launches the "
+                         "scan a few times and exits (no JSON line)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --same-device rehearses the N>1 control flow on a 1-GPU box")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -114,18 +121,27 @@ def free_port():
     return port
 
 
-def rank_log_path(rank):
-    """bench_rank{r}.err: every rank of an N > 1 run leaves its own evidence (device held, frames scanned, kernel
-    time, or the traceback that ended it) — under gpurun_out/ when that exists (it is what travels back from a
+def rank_log_dir(environ=None):
+    """Where the ranks of an N > 1 run leave their evidence: $MTGPU_BENCH_LOG_DIR if set (the launcher hands it to its
+    ranks; tests point it at a temporary directory), else gpurun_out/ when that exists (it is what travels back from a
     GPU box), else beside bench.py."""
+    environ = os.environ if environ is None else environ
+    if environ.get("MTGPU_BENCH_LOG_DIR"):
+        return environ["MTGPU_BENCH_LOG_DIR"]
     d = os.path.join(ROOT, "gpurun_out")
-    return os.path.join(d if os.path.isdir(d) else ROOT, f"bench_rank{rank}.err")
+    return d if os.path.isdir(d) else ROOT
 
 
-def rank_evidence(rank):
+def rank_log_path(rank, log_dir=None):
+    """bench_rank{r}.err: every rank of an N > 1 run leaves its own evidence (device held, frames scanned, kernel
+    time, or the traceback that ended it)."""
+    return os.path.join(log_dir or rank_log_dir(), f"bench_rank{rank}.err")
+
+
+def rank_evidence(rank, log_dir=None):
     """(bytes, newest mtime) over the files a rank writes while it lives: its stage log and its stderr file."""
     size, mtime = 0, 0.0
-    for path in (rank_log_path(rank), rank_log_path(rank) + ".stderr.log"):
+    for path in (rank_log_path(rank, log_dir), rank_log_path(rank, log_dir) + ".stderr.log"):
         try:
             st = os.stat(path)
         except OSError:
@@ -136,7 +152,7 @@ def rank_evidence(rank):
 
 
 def launch_ranks(a, argv, environ=None, popen=subprocess.Popen, clock=time.monotonic, sleep=time.sleep,
-                 evidence=rank_evidence, report=None):
+                 evidence=None, report=None, log_dir=None):
     """Start a.gpus fresh rank processes of this script (the parent never touches HIP, and no
     process that has is ever re-exec'ed), wait for all of them; rank 0's stdout (the JSON line)
     is ours.  Returns the exit code: non-zero if any rank failed.
@@ -146,8 +162,14 @@ def launch_ranks(a, argv, environ=None, popen=subprocess.Popen, clock=time.monot
     evidence has not grown for --rank-timeout seconds is hung (a collective that never completes, a rendezvous
     that never forms): every rank is terminated (killed 5 s later if it ignores that), the verdict is written to
     bench_launcher.err next to the rank logs, and the exit code is 124.  `clock`, `sleep`, `evidence` and
-    `popen` are injectable (tests/test_bench_contract.py)."""
+    `popen` are injectable (tests/test_bench_contract.py); `log_dir` is where the rank logs and bench_launcher.err
+    go (default: rank_log_dir()) — the ranks are told through MTGPU_BENCH_LOG_DIR."""
     environ = dict(os.environ if environ is None else environ)
+    log_dir = log_dir or rank_log_dir(environ)
+    environ["MTGPU_BENCH_LOG_DIR"] = log_dir
+    if evidence is None:
+        def evidence(r):
+            return rank_evidence(r, log_dir)
     envs = rank_environments(a.gpus, environ, free_port())
     cmd = [sys.executable, os.path.abspath(__file__)] + list(argv)
     limit = float(getattr(a, "rank_timeout", 0) or 0)
@@ -155,7 +177,7 @@ def launch_ranks(a, argv, environ=None, popen=subprocess.Popen, clock=time.monot
         def report(text):
             sys.stderr.write(text + "\n")
             try:
-                with open(os.path.join(os.path.dirname(rank_log_path(0)), "bench_launcher.err"), "a") as f:
+                with open(os.path.join(log_dir, "bench_launcher.err"), "a") as f:
                     f.write(text + "\n")
             except OSError:
                 pass
@@ -163,7 +185,7 @@ def launch_ranks(a, argv, environ=None, popen=subprocess.Popen, clock=time.monot
     # takes the run down: the reason must survive it, and the file's growth is a sign of life)
     procs = []
     for r, e in enumerate(envs):
-        for stale in (rank_log_path(r), rank_log_path(r) + ".stderr.log"):
+        for stale in (rank_log_path(r, log_dir), rank_log_path(r, log_dir) + ".stderr.log"):
             try:
                 os.remove(stale)
             except OSError:
@@ -171,7 +193,7 @@ def launch_ranks(a, argv, environ=None, popen=subprocess.Popen, clock=time.monot
         if r == 0:
             procs.append(popen(cmd, env=e, stdout=None))
         else:
-            with open(rank_log_path(r) + ".stderr.log", "wb") as errf:
+            with open(rank_log_path(r, log_dir) + ".stderr.log", "wb") as errf:
                 procs.append(popen(cmd, env=e, stdout=subprocess.DEVNULL, stderr=errf))
     rc = 0
     pending = {r: p for r, p in enumerate(procs)}
@@ -479,6 +501,93 @@ def load_calib():
         if fn(device, ptr, nbytes, shape, chunk, lds_bytes, idle_every, stream) != 0:
             raise RuntimeError("mtcalib_read_ceiling: " + lib.mtcalib_last_error().decode())
     return call
+
+
+PMC_KERNELS = ("scan_frames_kernel", "plan_scatter_kernel", "plan_count_kernel")     # one scan call = these launches
+
+
+def parse_pmc_dir(d, counter):
+    """(sum of `counter` over the library's kernels per scan launch, scan launches seen) from the
+    *_counter_collection.csv rocprofv3 wrote under `d`.  The planning kernels' bytes (offsets in, work list out) are
+    added to the scan kernel's: `traffic` is what one scan CALL moves."""
+    import csv
+    import glob
+    hits = sorted(glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True))
+    if not hits:
+        raise RuntimeError(f"no *_counter_collection.csv under {d}")
+    total, launches = 0.0, 0
+    for path in hits:
+        with open(path, newline="") as fh:
+            for row in csv.DictReader(fh):
+                if row.get("Counter_Name") != counter:
+                    continue
+                name = row.get("Kernel_Name", "")
+                if any(k in name for k in PMC_KERNELS):
+                    total += float(row["Counter_Value"])
+                    launches += "scan_frames_kernel" in name
+    if launches == 0:
+        raise RuntimeError(f"{counter}: no scan_frames_kernel dispatch in {d}")
+    return total / launches, launches
+
+
+def pmc_bytes(fetch_kb, write_kb):
+    """HBM bytes from the two counters as MI355X_MICROARCH.md (HBM section) prescribes for gfx950: unit KB, FETCH_SIZE
+    reports half the bytes of wide coalesced streaming reads (x2), WRITE_SIZE is exact."""
+    return fetch_kb * 1024.0 * 2.0 + write_kb * 1024.0
+
+
+def measure_traffic(a, argv, which=None, run=subprocess.run, tmp_root=None):
+    """roofline.traffic measured IN this run (N = 1): before this process touches the GPU, two fresh child processes
+    of this script run under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `... --pmc WRITE_SIZE` (separate passes,
+    no other trace domain, the interpreter directly after `--`: no env / shell / launcher hop), each building the
+    headline workload and launching the scan four times.  Returns (bytes per launch, source text, detail dict), or
+    (None, reason, None) when rocprofv3 is missing or a child fails — the caller then replays the committed figure."""
+    import shutil
+    import tempfile
+    which = which or shutil.which
+    exe = which("rocprofv3") or (os.path.exists("/opt/rocm/bin/rocprofv3") and "/opt/rocm/bin/rocprofv3")
+    if not exe:
+        return None, "rocprofv3 not found", None
+    child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--workload", a.workload, "--params", a.params,
+             "--frames", str(a.frames), "--distinct", str(a.distinct)]
+    out = {}
+    t0 = time.perf_counter()
+    with tempfile.TemporaryDirectory(dir=tmp_root or "/tmp") as tmp:
+        env = dict(os.environ, TMPDIR=tmp)
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "-f", "csv", "-d", d, "--"] + child
+            try:
+                r = run(cmd, cwd=tmp, env=env, capture_output=True, text=True, timeout=240)
+            except Exception as e:
+                return None, f"rocprofv3 --pmc {counter} child did not finish: {e!r}", None
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc {counter} child exited {r.returncode}: {(r.stderr or '')[-200:]}", None
+            try:
+                out[counter] = parse_pmc_dir(d, counter)
+            except Exception as e:
+                return None, f"rocprofv3 --pmc {counter}: {e}", None
+    (f_kb, nf), (w_kb, nw) = out["FETCH_SIZE"], out["WRITE_SIZE"]
+    detail = {"FETCH_SIZE_KB_raw": f_kb, "WRITE_SIZE_KB_raw": w_kb, "launches_averaged": [nf, nw],
+              "kernels_summed": list(PMC_KERNELS), "seconds": round(time.perf_counter() - t0, 1)}
+    return pmc_bytes(f_kb, w_kb), (
+        "measured in this run: two child processes of bench.py under rocprofv3 --kernel-trace --pmc FETCH_SIZE and "
+        "--pmc WRITE_SIZE (separate passes; gfx950: counter unit KB, FETCH_SIZE x2), mean over "
+        f"{nf} scan launches of the headline workload, planning kernels included"), detail
+
+
+def pmc_child(a):
+    """What rocprofv3 profiles for measure_traffic: the headline workload resident in HBM, four scan launches."""
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    w = build_workload(a.workload, a.params, a.frames, a.distinct, 1000, dev)
+    for _ in range(4):
+        w["scanner"].check_frames_device(w["d_mv"], w["d_off"], None, w["d_flags"])
+    torch.cuda.synchronize()
+    w["scanner"].close()
 
 
 def roofline_of(alg_bytes, kern_ms):
@@ -837,6 +946,14 @@ def _run_rank(a):
         # HBM bytes per launch: NOT measured by this run (PMC counters need rocprofv3 around the process) —
         # replayed from the committed summary of the builder's own --pmc passes over this same command
         traffic, traffic_source = replayed_traffic(a.workload, a.params, a.frames)
+        traffic_detail = None
+        measured = getattr(a, "pmc_result", None)
+        if measured and measured[0] is not None:
+            traffic_replayed = traffic
+            traffic, traffic_source, traffic_detail = measured
+            traffic_detail = dict(traffic_detail, replayed_figure_for_comparison=traffic_replayed)
+        elif measured:
+            traffic_source = (traffic_source or "no committed figure") + f" [not measured in this run: {measured[1]}]"
         cpu = None
         others = None
         host = None
@@ -875,12 +992,18 @@ def _run_rank(a):
             except Exception as e:          # e.g. out of memory on a smaller device: keep the headline
                 others = [{"error": repr(e)}]
         roof = roofline_of(alg_bytes, kern_ms)
-        roof.update({"traffic": traffic, "traffic_source": traffic_source, "measured_read_ceiling": read_ceiling,
+        roof.update({"traffic": traffic, "traffic_source": traffic_source, "traffic_detail": traffic_detail,
+                     "traffic_over_algorithmic": (traffic / alg_bytes) if traffic else None,
+                     "measured_read_ceiling": read_ceiling,
                      "measured_read_ceiling_is": f"best of a sweep of read-only kernels on the same buffer: {read_ceiling_best} "
                                                  "(load shape / bytes per workgroup [/ every n-th workgroup idle])",
                      "read_ceiling_sweep_GBps": {k_: round(v_, 1) for k_, v_ in sweep.items()},
                      "scan_rate_next_to_the_sweep_GBps": scan_in_sweep,
-                     "frac_of_measured_ceiling": scan_in_sweep / read_ceiling if read_ceiling else None})
+                     "frac_of_measured_ceiling": scan_in_sweep / read_ceiling if read_ceiling else None,
+                     # rounds 1-4 quoted this ratio instead: the timed loop's rate over ONE read-only kernel, 16 contiguous
+                     # bytes per lane, 1.25 MiB per workgroup (not the best of a sweep, not re-timed beside it)
+                     "frac_of_16B_read_kernel_rounds_1_to_4_definition":
+                         (roof["achieved"] / sweep["16B/1310720"]) if sweep.get("16B/1310720") else None})
         line = {
             "metric": "MV-scan frames/sec at 1080p grid" if a.workload.startswith("1080p") else "MV-scan frames/sec",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -1014,6 +1137,11 @@ def main(argv=None):
     a = parse(argv)
     if needs_launch(a, os.environ):
         sys.exit(launch_ranks(a, argv))
+    if a.pmc_child:
+        return pmc_child(a)
+    if a.gpus == 1 and "WORLD_SIZE" not in os.environ and not a.no_pmc and not a.force_dist:
+        # N = 1, and this process has not touched the GPU yet (torch is not even imported)
+        a.pmc_result = measure_traffic(a, argv)
     run_rank(a)
 
 

@@ -8,12 +8,24 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def gpurun_out_state():
+    """(path, size, mtime) of every file under gpurun_out/ — the evidence the GPU runs brought back, which no CPU test
+    may create, delete or append to."""
+    d = os.path.join(ROOT, "gpurun_out")
+    out = []
+    for base, _dirs, files in os.walk(d):
+        for f in files:
+            st = os.stat(os.path.join(base, f))
+            out.append((os.path.join(base, f), st.st_size, st.st_mtime_ns))
+    return sorted(out)
+
+
 def test_bench_refuses_to_run_without_gpu():
     import torch
     if torch.cuda.is_available():
         import pytest
         pytest.skip("a GPU is present")
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"],
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--no-pmc"],
                          capture_output=True, text=True)
     assert out.returncode != 0 and "needs a GPU" in (out.stderr + out.stdout)
     assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]      # no JSON line, no number
@@ -72,17 +84,22 @@ def test_bench_gpus_n_launches_n_ranks_itself(tmp_path):
             self.terminated = True
 
     fail_rank, fail_rank_code = -1, 0
-    assert bench.launch_ranks(a, argv, environ={"PATH": "/bin"}, popen=FakeProc) == 0
+    logs, reports = str(tmp_path / "logs"), []
+    os.makedirs(logs)
+    before = gpurun_out_state()
+    assert bench.launch_ranks(a, argv, environ={"PATH": "/bin"}, popen=FakeProc, log_dir=logs, report=reports.append) == 0
     assert len(started) == 4
     assert all(c[0][1].endswith("bench.py") and c[0][2:] == argv for c in started)
     assert started[0][2] is None and all(c[2] == subprocess.DEVNULL for c in started[1:])   # rank 0's stdout is ours
     # rank 0 keeps our stderr; every other rank's stderr is kept in its own file
     assert started[0][3] is None
-    assert [os.path.basename(c[3]) for c in started[1:]] == [f"bench_rank{r}.err.stderr.log" for r in (1, 2, 3)]
+    assert [c[3] for c in started[1:]] == [os.path.join(logs, f"bench_rank{r}.err.stderr.log") for r in (1, 2, 3)]
+    assert all(c[1]["MTGPU_BENCH_LOG_DIR"] == logs for c in started)             # the ranks log where the launcher looks
     assert len({c[1]["MASTER_PORT"] for c in started}) == 1
     started.clear()
     fail_rank, fail_rank_code = 2, 7
-    assert bench.launch_ranks(a, argv, environ={}, popen=FakeProc) == 7
+    assert bench.launch_ranks(a, argv, environ={}, popen=FakeProc, log_dir=logs, report=reports.append) == 7
+    assert len(reports) == 1 and "rank 2 exited with code 7" in reports[0]
 
     # end to end with real child processes: a tiny script in place of bench.py's rank body
     probe = tmp_path / "probe.py"
@@ -95,9 +112,13 @@ def test_bench_gpus_n_launches_n_ranks_itself(tmp_path):
     def probe_popen(cmd, env, stdout, stderr=None):
         return real_popen([sys.executable, str(probe)], env=env, stdout=subprocess.PIPE if stdout is None else stdout,
                           stderr=stderr)
-    assert bench.launch_ranks(bench.parse(["--gpus", "3"]), ["--gpus", "3"], environ=dict(os.environ), popen=probe_popen) == 0
+    assert bench.launch_ranks(bench.parse(["--gpus", "3"]), ["--gpus", "3"], environ=dict(os.environ), popen=probe_popen,
+                              log_dir=logs, report=reports.append) == 0
     assert bench.launch_ranks(bench.parse(["--gpus", "3"]), ["--gpus", "3"],
-                              environ=dict(os.environ, FAIL_RANK="1"), popen=probe_popen) == 3
+                              environ=dict(os.environ, FAIL_RANK="1"), popen=probe_popen, log_dir=logs, report=reports.append) == 3
+    # the default log directory is an environment setting away, and none of the above touched the evidence directory
+    assert bench.rank_log_dir({"MTGPU_BENCH_LOG_DIR": "/x/y"}) == "/x/y"
+    assert gpurun_out_state() == before
 
 
 def test_bench_helpers_traffic_quota_and_rank_logs():
@@ -128,7 +149,7 @@ def test_launcher_watchdog_ends_a_hung_run_and_keeps_the_evidence(tmp_path, monk
     ignores that), exit code 124, and a verdict line; a rank that keeps writing is never taken for hung."""
     sys.path.insert(0, ROOT)
     import bench
-    monkeypatch.setattr(bench, "rank_log_path", lambda r: str(tmp_path / f"bench_rank{r}.err"))
+    before = gpurun_out_state()
     now = [0.0]
     reports = []
 
@@ -162,7 +183,7 @@ def test_launcher_watchdog_ends_a_hung_run_and_keeps_the_evidence(tmp_path, monk
 
     a = bench.parse(["--gpus", "4", "--rank-timeout", "30"])
     rc = bench.launch_ranks(a, ["--gpus", "4"], environ={}, popen=Proc, clock=lambda: now[0], sleep=sleep,
-                            evidence=evidence, report=reports.append)
+                            evidence=evidence, report=reports.append, log_dir=str(tmp_path))
     assert rc == 124
     assert 30 < now[0] < 60                                                    # ended soon after the limit, not at 1000 s
     assert all(p.terminated for p in Proc.procs) and Proc.procs[1].killed      # SIGTERM for all, SIGKILL for the deaf one
@@ -174,7 +195,8 @@ def test_launcher_watchdog_ends_a_hung_run_and_keeps_the_evidence(tmp_path, monk
     now[0] = 0.0
     reports.clear()
     rc = bench.launch_ranks(a, ["--gpus", "4"], environ={}, popen=Proc, clock=lambda: now[0], sleep=sleep,
-                            evidence=lambda r: (0, 0.0) if r == 1 else (int(now[0] // 10), 0.0), report=reports.append)
+                            evidence=lambda r: (0, 0.0) if r == 1 else (int(now[0] // 10), 0.0), report=reports.append,
+                            log_dir=str(tmp_path))
     assert rc == 124 and 60 < now[0] < 90 and len(reports) == 1
     reports[:] = reports[:1]
 
@@ -187,12 +209,12 @@ def test_launcher_watchdog_ends_a_hung_run_and_keeps_the_evidence(tmp_path, monk
             return 0 if now[0] > 200 else None
     a = bench.parse(["--gpus", "2", "--rank-timeout", "30"])
     assert bench.launch_ranks(a, ["--gpus", "2"], environ={}, popen=Slow, clock=lambda: now[0], sleep=sleep,
-                              evidence=lambda r: (int(now[0] // 10), 0.0), report=reports.append) == 0
+                              evidence=lambda r: (int(now[0] // 10), 0.0), report=reports.append, log_dir=str(tmp_path)) == 0
     assert len(reports) == 1
     now[0] = 0.0
     a = bench.parse(["--gpus", "2", "--rank-timeout", "0"])
     assert bench.launch_ranks(a, ["--gpus", "2"], environ={}, popen=Slow, clock=lambda: now[0], sleep=sleep,
-                              evidence=lambda r: (0, 0.0), report=reports.append) == 0
+                              evidence=lambda r: (0, 0.0), report=reports.append, log_dir=str(tmp_path)) == 0
 
     # real processes: rank 1 sleeps "forever", the watchdog (1 s) ends the run; logs stay
     probe = tmp_path / "probe.py"
@@ -206,9 +228,11 @@ def test_launcher_watchdog_ends_a_hung_run_and_keeps_the_evidence(tmp_path, monk
     import time as _t
     t0 = _t.monotonic()
     a = bench.parse(["--gpus", "2", "--rank-timeout", "1"])
-    assert bench.launch_ranks(a, ["--gpus", "2"], environ=dict(os.environ), popen=probe_popen, report=reports.append) == 124
+    assert bench.launch_ranks(a, ["--gpus", "2"], environ=dict(os.environ), popen=probe_popen, report=reports.append,
+                              log_dir=str(tmp_path)) == 124
     assert _t.monotonic() - t0 < 20
     assert os.path.exists(str(tmp_path / "bench_rank1.err.stderr.log"))
+    assert gpurun_out_state() == before
 
 
 def test_rank_under_torchrun_sets_the_ipc_mode_before_the_gpu_runtime_starts():
@@ -237,3 +261,67 @@ def test_bench_line_config_is_machine_readable_when_truncated():
     assert len(wl) < 100 and "params=code_defaults" in wl
     assert 'f"{a.workload} params={a.params} grid=' in src and '"distinct_frames_tiled": a.distinct' in src
     assert '"vs_cpu_baseline_same_quota"' in src
+
+
+def test_traffic_is_measured_by_child_runs_or_the_fallback_says_why(tmp_path):
+    """roofline.traffic at N = 1: two rocprofv3 child runs (FETCH_SIZE, WRITE_SIZE in separate passes, the interpreter
+    directly after `--`), parsed from rocprofv3's counter CSVs with the guide's gfx950 correction; when rocprofv3 is
+    missing or a child fails the caller gets (None, reason) and replays the committed figure."""
+    sys.path.insert(0, ROOT)
+    import bench
+    a = bench.parse([])
+    assert not a.no_pmc and not a.pmc_child
+    # the parser: per scan launch, the scan kernel's counter plus the planning kernels' of the same call
+    d = tmp_path / "FETCH_SIZE" / "host" / "123"
+    d.mkdir(parents=True)
+    rows = ["Correlation_Id,Dispatch_Id,Kernel_Name,Counter_Name,Counter_Value"]
+    for i in range(3):
+        rows.append(f'{i},{3 * i},"void mtgpu::plan_scatter_kernel(...)",FETCH_SIZE,100')
+        rows.append(f'{i},{3 * i + 1},"void mtgpu::scan_frames_kernel<512, 4, 32, 0, 0, 40, false>(...)",FETCH_SIZE,10000000')
+        rows.append(f'{i},{3 * i + 1},"void mtgpu::scan_frames_kernel<512, 4, 32, 0, 0, 40, false>(...)",GRBM_COUNT,5')
+        rows.append(f'{i},{3 * i + 2},"void at::native::vectorized_elementwise_kernel<...>",FETCH_SIZE,777')
+    (d / "123_counter_collection.csv").write_text("\n".join(rows) + "\n")
+    assert bench.parse_pmc_dir(str(tmp_path / "FETCH_SIZE"), "FETCH_SIZE") == (10000100.0, 3)
+    assert bench.pmc_bytes(10000100.0, 50.0) == 10000100.0 * 2048.0 + 50.0 * 1024.0
+    import pytest
+    with pytest.raises(RuntimeError):
+        bench.parse_pmc_dir(str(tmp_path / "FETCH_SIZE"), "WRITE_SIZE")           # no dispatch carries that counter
+    # fallback 1: no rocprofv3 on the box (and none at the default ROCm path: patched out)
+    real_exists = os.path.exists
+    try:
+        os.path.exists = lambda p_: False if p_ == "/opt/rocm/bin/rocprofv3" else real_exists(p_)
+        t, why, detail = bench.measure_traffic(a, [], which=lambda name: None)
+    finally:
+        os.path.exists = real_exists
+    assert t is None and detail is None and "not found" in why
+    # fallback 2: a child fails; the command is rocprofv3 ... -- <python> bench.py --pmc-child (no hop in between)
+    seen = []
+
+    class R:
+        returncode, stderr = 1, "boom"
+
+    def run(cmd, **kw):
+        seen.append(cmd)
+        return R()
+    t, why, detail = bench.measure_traffic(a, [], which=lambda name: "/bin/rocprofv3", run=run, tmp_root=str(tmp_path))
+    assert t is None and "exited 1" in why and "boom" in why
+    cmd = seen[0]
+    assert cmd[0] == "/bin/rocprofv3" and cmd[1:4] == ["--kernel-trace", "--pmc", "FETCH_SIZE"]
+    assert not any(flag in cmd for flag in ("-s", "--sys-trace", "-r", "--runtime-trace", "--hip-trace", "--hsa-trace"))
+    sep = cmd.index("--")
+    assert cmd[sep + 1] == sys.executable and cmd[sep + 2].endswith("bench.py") and cmd[sep + 3] == "--pmc-child"
+    # success path with a stand-in child that writes the CSVs rocprofv3 would
+    def run_ok(cmd, **kw):
+        counter = cmd[cmd.index("--pmc") + 1]
+        out = os.path.join(cmd[cmd.index("-d") + 1], "h", "1")
+        os.makedirs(out)
+        with open(os.path.join(out, "1_counter_collection.csv"), "w") as fh:
+            fh.write("Kernel_Name,Counter_Name,Counter_Value\n")
+            for _ in range(4):
+                fh.write(f'"mtgpu::scan_frames_kernel<...>",{counter},{1000 if counter == "FETCH_SIZE" else 10}\n')
+
+        class Ok:
+            returncode, stderr = 0, ""
+        return Ok()
+    t, src, detail = bench.measure_traffic(a, [], which=lambda name: "/bin/rocprofv3", run=run_ok, tmp_root=str(tmp_path))
+    assert t == 1000 * 2048.0 + 10 * 1024.0 and src.startswith("measured in this run") and detail["launches_averaged"] == [4, 4]
