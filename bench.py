@@ -302,24 +302,27 @@ def build_workload(workload, params_name, frames, distinct, seed, dev, arena=Non
 
 
 def time_scan_only(w, steps, warmup=3):
-    """Scan kernel alone, HIP events on the launch stream (torch's current stream is passed to the
-    C ABI explicitly).  Returns mean kernel ms."""
+    """One scan call per step, back to back on torch's current stream, timed by the library's own HIP events on that
+    stream (mtgpu_profile_enable: before the planning kernels, between them and the scan kernel, after it).  Returns
+    the mean SCAN KERNEL ms; w["plan_ms"] = mean ms of the planning kernels ahead of it."""
     import torch
     s = w["scanner"]
     for _ in range(warmup):
         s.check_frames_device(w["d_mv"], w["d_off"], None, w["d_flags"])
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
-    for e0, e1 in ev:
-        e0.record()
+    s.profile(True)
+    for _ in range(steps):
         s.check_frames_device(w["d_mv"], w["d_off"], None, w["d_flags"])
-        e1.record()
+    pr = s.profile_read()
+    s.profile(False)
     torch.cuda.synchronize()
-    return float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))
+    assert pr["launches"] == steps
+    w["plan_ms"] = pr["plan_ms"]
+    return pr["scan_ms"]
 
 
 def time_compact(w, steps, warmup=3):
     """The same batch as 8-byte compact records (what the host dispatcher stages), resident in HBM:
-    mtgpu_scan_frames_device_compact.  Returns (mean kernel ms, flags)."""
+    mtgpu_scan_frames_device_compact.  Returns (mean scan kernel ms, mean planning ms, flags)."""
     import torch
     import mvtrim_amd as m
     s = w["scanner"]
@@ -330,13 +333,13 @@ def time_compact(w, steps, warmup=3):
     flags = torch.empty(w["frames"], dtype=torch.uint8, device=w["d_off"].device)
     for _ in range(warmup):
         s.check_frames_device_compact(d_rec, w["d_off"], None, flags)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
-    for e0, e1 in ev:
-        e0.record()
+    s.profile(True)
+    for _ in range(steps):
         s.check_frames_device_compact(d_rec, w["d_off"], None, flags)
-        e1.record()
+    pr = s.profile_read()
+    s.profile(False)
     torch.cuda.synchronize()
-    return float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev])), flags.cpu().numpy()
+    return pr["scan_ms"], pr["plan_ms"], flags.cpu().numpy()
 
 
 def host_fed_leg(spec, mv, off):
@@ -620,8 +623,9 @@ def other_workloads(dev, distinct, arena=None):
         out.append({"workload": f"synthetic {wl} MV arrays, {p.grid_w}x{p.grid_h} grid, {frames} frames "
                                 f"({dd} distinct tiled), params={pn}"
                                 + (" with VECTORS_NEEDED 1 (one record per cell)" if p.vectors_needed == 1 and pn == "code_defaults" else ""),
-                    "frames_per_s": frames / (kern_ms * 1e-3), "kernel_ms": kern_ms, "steps": steps,
-                    "achieved_GBps": r["achieved"], "frac": r["frac"], "plan": w["scanner"].plan,
+                    "frames_per_s": frames / ((kern_ms + w["plan_ms"]) * 1e-3), "kernel_ms": kern_ms, "plan_ms": w["plan_ms"],
+                    "steps": steps, "achieved_GBps": r["achieved"], "frac": r["frac"],
+                    "frac_of_call": r["achieved"] * kern_ms / (kern_ms + w["plan_ms"]) / HBM_PEAK_GBS, "plan": w["scanner"].plan,
                     "algorithmic_bytes_per_launch": w["alg_bytes"],
                     "traffic": replayed_traffic(wl, pn, frames)[0],
                     "traffic_source": replayed_traffic(wl, pn, frames)[1],
@@ -635,12 +639,13 @@ def other_workloads(dev, distinct, arena=None):
         try:
             w = build_workload("1080p_dense8x8", "code_defaults", cframes, min(distinct, 60), 1000, dev, arena)
             ref_ms = time_scan_only(w, 10)
-            k8, f8 = time_compact(w, 40)
+            k8, p8, f8 = time_compact(w, 40)
             assert np.array_equal(f8, w["d_flags"].cpu().numpy()), "compact flags differ from the 40-byte scan"
             cbytes = 8 * w["n_records"] + 9 * w["frames"]
             out.append({"workload": f"synthetic 1080p_dense8x8 as COMPACT 8-byte records (src/dst int16 x4), {cframes} frames",
                         "frames_per_s": w["frames"] / (k8 * 1e-3), "kernel_ms": k8, "steps": 40,
                         "achieved_GBps": cbytes / (k8 * 1e-3) / 1e9, "frac": cbytes / (k8 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "plan_ms": p8, "frac_of_call": cbytes / ((k8 + p8) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         "bytes_per_launch": cbytes, "speedup_vs_40_byte_records": ref_ms / k8})
             w["scanner"].close()
             del w
@@ -654,7 +659,7 @@ def other_workloads(dev, distinct, arena=None):
         rates = {}
         for name, gop in (("no_key_frames", 0), ("key_frame_every_8", 8), ("no_key_frames_again", 0), ("key_frame_every_8_again", 8)):
             w = build_workload("1080p_dense8x8", "code_defaults", 4096 if gop == 0 else 4680, 64, 1000, dev, arena, gop=gop)
-            ms = time_scan_only(w, 10)
+            ms = time_scan_only(w, 10) + w["plan_ms"]           # the whole call: planning kernels + scan kernel
             fl = w["d_flags"].cpu().numpy()
             assert np.array_equal(fl, np.tile(fl[:64], w["reps"])[: w["frames"]]), "flags are not tile-periodic"
             rates[name] = w["alg_bytes"] / (ms * 1e-3) / 1e9
@@ -801,8 +806,6 @@ def _run_rank(a):
     d_mp = torch.from_numpy(mp.view(np.uint8).copy()).to(dev)
     SEG_CAP = 64
 
-    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps)]
-    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps)]
     # two sets of merge outputs / gather buffers: the gather of step i overlaps the scan of step i+1
     packed_w = SEG_CAP * 16 + m.MERGE_RESULT_DTYPE.itemsize
     outs = [(torch.zeros((S, SEG_CAP, 2), dtype=torch.float64, device=dev),
@@ -827,11 +830,8 @@ def _run_rank(a):
         counter[0] += 1
         if merge_done[k] is not None:
             scan_stream.wait_event(merge_done[k])
-        if i is not None:
-            ev0[i].record()
+        # (timed by the library's own event triple on this stream: mtgpu_profile_enable below)
         scanner.check_frames_device(d_mv, d_off, None, flag_bufs[k])
-        if i is not None:
-            ev1[i].record()
         if a.no_merge:
             return None
         scan_done[k].record(scan_stream)
@@ -866,6 +866,9 @@ def _run_rank(a):
         step()
     finish()
     torch.cuda.synchronize()
+    # HIP events on the launch stream, recorded by the library around its kernels: before the planning kernels,
+    # between them and the scan kernel, after the scan kernel — one more marker per step than an event pair around the call
+    scanner.profile(True)
     stage("warm")
     if multi:
         dist.barrier()
@@ -886,7 +889,10 @@ def _run_rank(a):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in zip(ev0, ev1)]))
+    prof = scanner.profile_read()
+    scanner.profile(False)
+    assert prof["launches"] == a.steps, prof
+    kern_ms, plan_ms = prof["scan_ms"], prof["plan_ms"]
     # calibration (outside the timed region): kernels that ONLY read the same record buffer — both load shapes, three
     # chunk sizes, 20 launches back to back each (the regime of the timed loop); the ceiling is the best of them
     calib = load_calib()
@@ -992,6 +998,10 @@ def _run_rank(a):
             except Exception as e:          # e.g. out of memory on a smaller device: keep the headline
                 others = [{"error": repr(e)}]
         roof = roofline_of(alg_bytes, kern_ms)
+        # the planning kernels ahead of every scan (frames without side data answered, the others listed): their time,
+        # and the rate of the whole call — what a caller of mtgpu_scan_frames_device gets per launch
+        roof.update({"plan_ms": plan_ms, "call_ms": kern_ms + plan_ms,
+                     "frac_of_call": alg_bytes / ((kern_ms + plan_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS})
         roof.update({"traffic": traffic, "traffic_source": traffic_source, "traffic_detail": traffic_detail,
                      "traffic_over_algorithmic": (traffic / alg_bytes) if traffic else None,
                      "measured_read_ceiling": read_ceiling,

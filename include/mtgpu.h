@@ -122,6 +122,16 @@ int mtgpu_get_stats(mtgpu_ctx *ctx, mtgpu_ctx_stats *out);
  * safe at any time, from any thread; scans that follow simply map scratch again. */
 int mtgpu_trim(mtgpu_ctx *ctx);
 
+/* Launch timing — a profiling aid, off by default.  While on, every scan launched through the context records three
+ * HIP events on its stream: before the planning kernels (which answer the frames without side data and list the
+ * others), between them and the scan kernel, after the scan kernel — from a ring of 64 triples (a launch that finds
+ * the ring full first waits for the oldest one).  mtgpu_profile_read waits for the launches recorded so far, adds up
+ * their times (*plan_ms, *scan_ms: totals over *launches launches) and starts over.  bench.py uses it to time the
+ * scan kernel by itself, as `rocprofv3 --kernel-trace --stats` does.  For one user at a time: launches of a context
+ * that is being profiled are serialised on the host. */
+int mtgpu_profile_enable(mtgpu_ctx *ctx, int on);
+int mtgpu_profile_read(mtgpu_ctx *ctx, double *plan_ms, double *scan_ms, uint32_t *launches);
+
 /* Launch plan chosen for the context's grid (for reports and tests). */
 typedef struct mtgpu_plan {
   int32_t block_threads;   /* workgroup size                                      */

@@ -90,6 +90,8 @@ ABI = {
     "mtgpu_trim": (C.c_int, [C.c_void_p]),
     "mtgpu_get_plan": (C.c_int, [C.c_void_p, C.POINTER(PlanC)]),
     "mtgpu_plan_preview": (C.c_int, [C.POINTER(ScanParamsC), C.c_int, C.c_int, C.POINTER(PlanC)]),
+    "mtgpu_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "mtgpu_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
     "mtgpu_set_slices": (C.c_int, [C.c_void_p, C.c_int]),
     "mtgpu_scan_frames_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p,
                                            C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),

@@ -100,6 +100,29 @@ struct mtgpu_ctx {
   std::mutex pipe_mu;
   std::mutex mu;         // guards the staging buffers below
   DevBuf d_mv, d_off, d_sd, d_flags, d_misc;
+  // launch timing (mtgpu_profile_enable): a ring of event triples {before planning, planned, scanned}
+  struct Profile {
+    static constexpr int kRing = 64;
+    std::atomic<int> on{0};
+    std::mutex mu;                       // held across a profiled launch
+    hipEvent_t ev[kRing][3] = {};
+    bool created = false;
+    int tail = 0, count = 0;             // outstanding triples: tail .. tail + count - 1 (mod kRing)
+    double plan_ms = 0.0, scan_ms = 0.0;
+    uint32_t launches = 0;
+    // waits for the oldest outstanding triple and adds its times up (mu held)
+    hipError_t drain_one() {
+      hipEvent_t *t = ev[tail];
+      hipError_t e = hipEventSynchronize(t[2]);
+      if (e != hipSuccess) return e;
+      float a = 0.f, b = 0.f;
+      if ((e = hipEventElapsedTime(&a, t[0], t[1])) != hipSuccess) return e;
+      if ((e = hipEventElapsedTime(&b, t[1], t[2])) != hipSuccess) return e;
+      plan_ms += a; scan_ms += b; ++launches;
+      tail = (tail + 1) % kRing; --count;
+      return hipSuccess;
+    }
+  } prof;
 };
 
 namespace {
@@ -400,7 +423,16 @@ int launch_scan_on(mtgpu_ctx *c, const void *d_mv, uint64_t n_records, const uin
   if (L.k.slices > 1)
     bytes += sizeof(unsigned int) * ((size_t)n_frames * (size_t)L.k.slices * (size_t)L.k.cnt_words + (size_t)n_frames + 4);
   void *scratch = nullptr;
-  hipError_t e = scratch_alloc(c, &scratch, bytes, st);
+  hipError_t e = hipSuccess;
+  static void *exp_cached = nullptr;                  // experiments build, MTGPU_PLAN_CACHE=1: ONE process-wide scratch block,
+  static size_t exp_cached_bytes = 0;                 // never freed — measures what the stream-ordered alloc/free pair costs
+  const bool exp_cache = mtgpu::kExperiments && exp_int("MTGPU_PLAN_CACHE", 0) != 0;
+  if (exp_cache) {
+    if (exp_cached_bytes < bytes) { (void)hipMalloc(&exp_cached, bytes * 2); exp_cached_bytes = bytes * 2; }
+    scratch = exp_cached;
+  } else {
+    e = scratch_alloc(c, &scratch, bytes, st);
+  }
   if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(scan scratch)");
   L.plan_ws = scratch;
   unsigned int *rest = reinterpret_cast<unsigned int *>(static_cast<unsigned char *>(scratch) + plan_bytes);
@@ -409,9 +441,27 @@ int launch_scan_on(mtgpu_ctx *c, const void *d_mv, uint64_t n_records, const uin
     L.slice_ws = rest;
     L.tickets = L.slice_ws + (((size_t)n_frames * (size_t)L.k.slices * (size_t)L.k.cnt_words + 3) & ~(size_t)3);
   }
-  e = mtgpu::launch_scan(L);
+  L.ev_planned = nullptr;
   int rc = MT_OK;
+  if (c->prof.on.load(std::memory_order_relaxed)) {
+    mtgpu_ctx::Profile &pf = c->prof;
+    std::lock_guard<std::mutex> lock(pf.mu);
+    if (pf.created && pf.count == mtgpu_ctx::Profile::kRing) e = pf.drain_one();
+    if (e == hipSuccess && pf.created) {
+      hipEvent_t *t = pf.ev[(pf.tail + pf.count) % mtgpu_ctx::Profile::kRing];
+      e = hipEventRecord(t[0], st);
+      L.ev_planned = t[1];
+      if (e == hipSuccess) e = mtgpu::launch_scan(L);
+      if (e == hipSuccess) e = hipEventRecord(t[2], st);
+      if (e == hipSuccess) ++pf.count;
+    } else if (e == hipSuccess) {
+      e = mtgpu::launch_scan(L);
+    }
+  } else {
+    e = mtgpu::launch_scan(L);
+  }
   if (e != hipSuccess) rc = hip_fail(e, "scan launch");
+  if (exp_cache) return rc;
   hipError_t e2 = hipFreeAsync(scratch, st);
   if (rc == MT_OK && e2 != hipSuccess) rc = hip_fail(e2, "hipFreeAsync");
   return rc;
@@ -572,6 +622,9 @@ void mtgpu_destroy(mtgpu_ctx *c) {
   if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
   for (hipStream_t &ps : c->pipe_streams)            // (pipes are destroyed before their context: include/mtgpu.h)
     if (ps) { (void)hipStreamSynchronize(ps); (void)hipStreamDestroy(ps); ps = nullptr; }
+  for (auto &t : c->prof.ev)
+    for (hipEvent_t &e : t)
+      if (e) { (void)hipEventDestroy(e); e = nullptr; }
   if (c->pool) { (void)hipDeviceSynchronize(); (void)hipMemPoolDestroy(c->pool); }
   c->d_mv.release(); c->d_off.release(); c->d_sd.release(); c->d_flags.release(); c->d_misc.release();
   delete c;
@@ -716,6 +769,34 @@ int mtgpu_pack_records_with(int impl_flags, const void *mv_bytes, uint64_t n_rec
 }
 
 int mtgpu_pack_selected(void) { return mtgpu::pack_selected(); }
+
+int mtgpu_profile_enable(mtgpu_ctx *c, int on) {
+  if (!c) return fail(MT_ERR_INVALID, "ctx is NULL");
+  mtgpu_ctx::Profile &pf = c->prof;
+  std::lock_guard<std::mutex> lock(pf.mu);
+  if (on && !pf.created) {
+    HIP_TRY(hipSetDevice(c->device));
+    for (auto &t : pf.ev)
+      for (hipEvent_t &e : t) HIP_TRY(hipEventCreate(&e));       // (a failure leaves what was created to mtgpu_destroy)
+    pf.created = true;
+  }
+  pf.on.store(on ? 1 : 0, std::memory_order_relaxed);
+  return MT_OK;
+}
+
+int mtgpu_profile_read(mtgpu_ctx *c, double *plan_ms, double *scan_ms, uint32_t *launches) {
+  if (!c || !plan_ms || !scan_ms || !launches) return fail(MT_ERR_INVALID, "NULL argument");
+  mtgpu_ctx::Profile &pf = c->prof;
+  std::lock_guard<std::mutex> lock(pf.mu);
+  while (pf.count > 0) {
+    const hipError_t e = pf.drain_one();
+    if (e != hipSuccess) return hip_fail(e, "profile events");
+  }
+  *plan_ms = pf.plan_ms; *scan_ms = pf.scan_ms; *launches = pf.launches;
+  pf.plan_ms = pf.scan_ms = 0.0;
+  pf.launches = 0;
+  return MT_OK;
+}
 
 int mtgpu_set_slices(mtgpu_ctx *c, int slices) {
   if (!c) return fail(MT_ERR_INVALID, "ctx is NULL");

@@ -88,6 +88,7 @@ struct ScanLaunch {
   int device;
   int rec_bytes;           // 40 = AVMotionVector records, 8 = compact {src_x,src_y,dst_x,dst_y}
   hipStream_t stream;
+  hipEvent_t ev_planned;   // profiling (mtgpu_profile_enable): recorded between the planning kernels and the scan kernel; else nullptr
 };
 
 hipError_t launch_scan(const ScanLaunch &L);

@@ -982,45 +982,48 @@ __global__ __launch_bounds__(kPlanBlock) void plan_scatter_kernel(
     const unsigned int *__restrict__ blk_cnt, WorkItem *__restrict__ work, unsigned char *__restrict__ flags, int sys_flags,
     unsigned int *next_ticket) {
   constexpr unsigned int WAVES = kPlanBlock / 64u;
-  __shared__ unsigned int before;                // frames with side data in the blocks before this one
-  __shared__ unsigned int wave_cnt[WAVES];
+  __shared__ unsigned int wave_before[WAVES];    // frames with side data in the blocks before this one, as each wave counted them
+  __shared__ unsigned int wave_cnt[2][WAVES];    // ... among this iteration's frames, per wave (double-buffered: one barrier per iteration)
   const unsigned int tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  if (tid == 0u) before = 0u;
-  __syncthreads();
-  if (blockIdx.x != 0u) {
-    unsigned int mine = 0u;
+  // this block's first frames: loaded before the counting below, so that both wait for memory once
+  unsigned long long f = (unsigned long long)blockIdx.x * per * kPlanBlock + tid;
+  unsigned long long r0 = 0ull, r1 = 0ull;
+  bool valid = f < n_frames;
+  bool sd = valid && plan_frame(frame_off, has_sd, n_records, f, r0, r1);
+  {
+    unsigned int mine = 0u;                      // every lane ends up with its wave's count
     if (blk_cnt) {
       for (unsigned int j = tid; j < blockIdx.x; j += kPlanBlock) mine += blk_cnt[j];
-      if (mine) atomicAdd(&before, mine);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) mine += (unsigned int)__shfl_xor((int)mine, o);
     } else {                                     // fused form (per == 1): count the frames of the blocks before this one
       // (blockIdx.x whole blocks of kPlanBlock frames: the trip count is uniform; four blocks' loads in flight per step)
       for (unsigned int j = 0; j < blockIdx.x; j += 4u) {
-        bool sd[4];
+        bool s4[4];
 #pragma unroll
         for (unsigned int u = 0; u < 4u; ++u) {
-          unsigned long long r0, r1;
-          sd[u] = (j + u < blockIdx.x) && plan_frame(frame_off, has_sd, n_records, (unsigned long long)(j + u) * kPlanBlock + tid, r0, r1);
+          unsigned long long a0, a1;
+          s4[u] = (j + u < blockIdx.x) && plan_frame(frame_off, has_sd, n_records, (unsigned long long)(j + u) * kPlanBlock + tid, a0, a1);
         }
 #pragma unroll
-        for (unsigned int u = 0; u < 4u; ++u) mine += (unsigned int)__popcll(__ballot(sd[u]));
+        for (unsigned int u = 0; u < 4u; ++u) mine += (unsigned int)__popcll(__ballot(s4[u]));
       }
-      if (lane == 0u && mine) atomicAdd(&before, mine);                     // every lane holds its wave's count
     }
-    __syncthreads();
+    if (lane == 0u) wave_before[wave] = mine;
   }
-  unsigned int running = before;                 // frames with side data before the frames of this iteration
+  unsigned int running = 0u;                     // frames with side data before the frames of this iteration
   for (unsigned int i = 0; i < per; ++i) {
-    const unsigned long long f = ((unsigned long long)blockIdx.x * per + i) * kPlanBlock + tid;
-    unsigned long long r0 = 0ull, r1 = 0ull;
-    const bool valid = f < n_frames;
-    const bool sd = valid && plan_frame(frame_off, has_sd, n_records, f, r0, r1);
     const unsigned long long b = __ballot(sd);
-    if (lane == 0u) wave_cnt[wave] = (unsigned int)__popcll(b);
-    __syncthreads();
+    if (lane == 0u) wave_cnt[i & 1u][wave] = (unsigned int)__popcll(b);
+    __syncthreads();                             // (also publishes wave_before, first iteration)
+    if (i == 0u) {
+#pragma unroll
+      for (unsigned int w = 0; w < WAVES; ++w) running += wave_before[w];
+    }
     unsigned int below = 0u, all = 0u;           // waves before this one; the whole block
 #pragma unroll
     for (unsigned int w = 0; w < WAVES; ++w) {
-      const unsigned int c = wave_cnt[w];
+      const unsigned int c = wave_cnt[i & 1u][w];
       below += w < wave ? c : 0u;
       all += c;
     }
@@ -1038,7 +1041,11 @@ __global__ __launch_bounds__(kPlanBlock) void plan_scatter_kernel(
       }
     }
     running += all;
-    __syncthreads();                             // wave_cnt is rewritten by the next iteration
+    if (i + 1u < per) {                          // the next kPlanBlock frames of this block
+      f += kPlanBlock;
+      valid = f < n_frames;
+      sd = valid && plan_frame(frame_off, has_sd, n_records, f, r0, r1);
+    }
   }
   if (blockIdx.x == 0 && tid == 0) {
     WorkItem it;
@@ -1196,6 +1203,7 @@ hipError_t launch_scan(const ScanLaunch &L) {
     unsigned int *blk_cnt = reinterpret_cast<unsigned int *>(work + (size_t)L.n_frames + 1u);
     e = launch_plan(L, work, blk_cnt, blk_cnt + plan_blocks(L.n_frames));
     if (e != hipSuccess) return e;
+    if (L.ev_planned && (e = hipEventRecord(L.ev_planned, L.stream)) != hipSuccess) return e;
   }
   switch (L.block) {
 #ifdef MTGPU_EXPERIMENTS

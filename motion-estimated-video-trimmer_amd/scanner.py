@@ -235,6 +235,17 @@ class MotionScanner:
         """Workgroups per frame: 0 = automatic (default), or 1 / 2 / 4 / 8.  Never changes results."""
         check(self._lib.mtgpu_set_slices(self._ctx, int(slices)))
 
+    def profile(self, on: bool = True):
+        """Launch timing on / off (mtgpu_profile_enable): three events per scan launch, read with profile_read()."""
+        check(self._lib.mtgpu_profile_enable(self._ctx, 1 if on else 0))
+
+    def profile_read(self) -> dict:
+        """Waits for the profiled launches so far; {"plan_ms", "scan_ms"}: MEAN per launch over "launches" launches."""
+        a, b, n = C.c_double(), C.c_double(), C.c_uint32()
+        check(self._lib.mtgpu_profile_read(self._ctx, C.byref(a), C.byref(b), C.byref(n)))
+        k = max(n.value, 1)
+        return {"plan_ms": a.value / k, "scan_ms": b.value / k, "launches": n.value}
+
     def stats(self) -> dict:
         """What the context holds on the device (mtgpu_get_stats): staging of the host-pointer entry points,
         the scratch pool's reserved bytes now and at its high-water mark."""

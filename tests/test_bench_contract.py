@@ -130,7 +130,7 @@ def test_bench_helpers_traffic_quota_and_rank_logs():
     a = bench.parse([])
     t, src = bench.replayed_traffic(a.workload, a.params, a.frames)
     assert t and 1.0 <= t / (40 * 15837 * 32640 + 9 * 16384) < 1.001        # 16 384 frames: 15 837 P-frames x 32 640 records
-    assert src.startswith("replayed, not measured in this run") and "pmc_traffic.json" in src and "round 5" in src
+    assert src.startswith("replayed, not measured in this run") and "pmc_traffic.json" in src and "round 6" in src
     for (wl, pn, frames, _steps) in bench.OTHER_WORKLOADS:
         t, src = bench.replayed_traffic(wl, pn, frames)
         assert t and "replayed" in src, (wl, pn, frames)

@@ -1304,6 +1304,91 @@ def test_one_context_entered_from_many_threads(gpu_scanner_factory):
     assert not errors, errors
 
 
+def test_settings_change_while_other_threads_scan(gpu_scanner_factory):
+    """mtgpu_set_slices and mtgpu_profile_enable may be called on a context that other threads are scanning through
+    (the host layer shares one context per (device, parameters) across S x T workers; the reference enters its
+    scanner from N workers at once, src/pipeline.cpp:186-197): four threads scan device-resident batches — few large
+    frames, so that the slices setting really changes the launch — while a fifth keeps changing both settings;
+    every flag equals the oracle's, every time."""
+    import threading
+    import torch
+    spec = synth.spec_4k(seed=31, sub=2)
+    spec.events = synth.scripted_events(spec, 40)
+    p = ob.params_from_config(3840, 2160)
+    s = gpu_scanner_factory(p)
+    errors, lock, stop = [], threading.Lock(), threading.Event()
+
+    def scan(w):
+        try:
+            frames = [synth.gen_frame(spec, 30 + (w * 3 + i) % 10) for i in range(6)]
+            b = m.FrameBatch.from_frames(frames)
+            want = ob.scan_frames(p, b.mv, b.frame_off, b.has_sd)
+            st = torch.cuda.Stream()
+            d_mv = torch.from_numpy(b.mv.view(np.uint8).reshape(-1).copy()).cuda()
+            d_off = torch.from_numpy(b.frame_off.astype(np.int64)).cuda()
+            d_sd = torch.from_numpy(b.has_sd).cuda()
+            torch.cuda.synchronize()
+            for _ in range(40):
+                got = s.check_frames_device(d_mv, d_off, d_sd, stream=st.cuda_stream)
+                st.synchronize()
+                assert np.array_equal(got.cpu().numpy(), want)
+        except BaseException as e:          # noqa: BLE001 - reported to the main thread
+            with lock:
+                errors.append((w, repr(e)))
+
+    def toggle():
+        k = 0
+        while not stop.is_set():
+            s.set_slices((0, 1, 2, 4, 8)[k % 5])
+            s.profile(k % 3 == 0)
+            if k % 7 == 0:
+                s.profile_read()
+            k += 1
+
+    threads = [threading.Thread(target=scan, args=(w,)) for w in range(4)]
+    tg = threading.Thread(target=toggle)
+    tg.start()
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    stop.set()
+    tg.join()
+    s.set_slices(0)
+    s.profile(False)
+    s.profile_read()
+    assert not errors, errors
+
+
+def test_launch_timing_events(gpu_scanner_factory):
+    """mtgpu_profile_enable / mtgpu_profile_read: one event triple per scan launch (planning | scan kernel), a ring of
+    64 that a 65th launch drains by itself, totals reset by every read, nothing recorded while off."""
+    import torch
+    spec = synth.spec_1080p(seed=3, sub=2)
+    spec.events = synth.scripted_events(spec, 40)
+    mv, off, pts, sd = synth.gen_stream(spec, 40)
+    p = ob.params_from_config(1920, 1080)
+    s = gpu_scanner_factory(p)
+    want = ob.scan_frames(p, mv, off, sd)
+    d_mv = torch.from_numpy(mv.view(np.uint8).copy()).cuda()
+    d_off = torch.from_numpy(off.astype(np.int64)).cuda()
+    d_sd = torch.from_numpy(sd).cuda()
+    s.check_frames_device(d_mv, d_off, d_sd)
+    assert s.profile_read()["launches"] == 0                  # off: nothing recorded
+    s.profile(True)
+    for n in (5, 70):                                         # 70 > the ring of 64
+        for _ in range(n):
+            got = s.check_frames_device(d_mv, d_off, d_sd)
+        pr = s.profile_read()
+        assert pr["launches"] == n and 0.0 < pr["plan_ms"] < pr["scan_ms"] < 50.0, pr
+        assert np.array_equal(got.cpu().numpy(), want)
+    assert np.array_equal(s.check_frames(m.FrameBatch(mv, off, None, sd)), want)      # the host-pointer entry is timed too
+    assert s.profile_read()["launches"] == 1
+    s.profile(False)
+    s.check_frames_device(d_mv, d_off, d_sd)
+    assert s.profile_read() == {"plan_ms": 0.0, "scan_ms": 0.0, "launches": 0}
+
+
 @pytest.mark.parametrize("job", [False, True])
 def test_merge_extreme_finite_values(gpu_scanner_factory, job):
     """Timestamps and merge constants at the edges of binary64 (denormals, 1e308, negative times, a
