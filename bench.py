@@ -74,6 +74,9 @@ def parse(argv=None):
     ap.add_argument("--no-merge", action="store_true", help="time the scan kernel alone")
     ap.add_argument("--no-others", action="store_true", help="skip the other_workloads leg")
     ap.add_argument("--no-host", action="store_true", help="skip the host-fed (PCIe-inclusive) leg")
+    ap.add_argument("--host-runs", type=int, default=3,
+                    help="host-fed config-4 shapes: long runs per shape (median / min / max are reported; 0 = the short cold-start run only)")
+    ap.add_argument("--host-seconds", type=float, default=15.0, help="... and the least wall time of each long run")
     ap.add_argument("--no-pmc", action="store_true",
                     help="do not measure roofline.traffic with rocprofv3 child runs (N = 1 only; the committed figure is replayed)")
     ap.add_argument("--pmc-child", action="store_true",
@@ -342,12 +345,13 @@ def time_compact(w, steps, warmup=3):
     return pr["scan_ms"], pr["plan_ms"], flags.cpu().numpy()
 
 
-def host_fed_leg(spec, mv, off):
+def host_fed_leg(spec, mv, off, runs=3, seconds=15.0):
     """PCIe-inclusive rate of the host dispatcher (never `value`): the C++ front end mtgpu_scan_file
-    fed by 16 worker threads from a 12-frame stream of the headline workload repeated 500x (MV
+    fed by 16 worker threads from a 12-frame stream of the headline workload presented many times (MV
     bytes cache-resident, as when a decoder thread has just written them), with the default
     staging (8-byte compact records, zero-copy) and with round 1's path (40-byte records, H2D
-    copies).  Separate processes; a few seconds."""
+    copies): three runs each (separate processes, ~2 s of scanning), median / min / max.  Then BASELINE
+    config 4 (host_fed_batch64): a cold start and `runs` runs of >= `seconds` per shape."""
     import tempfile
     import mvtrim_amd as m
     exe = os.path.join(ROOT, "motion-estimated-video-trimmer_amd", "mtgpu_scan_file")
@@ -357,7 +361,7 @@ def host_fed_leg(spec, mv, off):
     # page-locks its 2nd and 3rd batch on first use, i.e. INSIDE that window (16 workers x 2 x 16 MiB = 0.1 s at the
     # driver's ~5 GB/s): rounds 2-3 ran 6000 frames (35 ms of work), which now measures the page-locking, not the feed
     n, workers = 12, min(16, len(os.sched_getaffinity(0)))
-    reps_of = {"compact8_zero_copy": 10000, "aos40_copy": 3000}
+    reps_of = {"compact8_zero_copy": 30000, "aos40_copy": 6000}          # about 2 s of scanning per run each
     frames = [mv[int(off[i]):int(off[i + 1])] for i in range(1, 1 + n)]       # P-frames 1..12 of the tile
     out = {"source": f"{n}-frame 1080p dense8x8 stream repeated {reps_of['compact8_zero_copy']}x / {reps_of['aos40_copy']}x "
                      f"({n * reps_of['compact8_zero_copy']} / {n * reps_of['aos40_copy']} frames), cache-resident",
@@ -372,16 +376,18 @@ def host_fed_leg(spec, mv, off):
             env.pop("MTGPU_BATCH_MB", None)
             # one GPU only (the host layer would spread its workers over every visible device)
             env["HIP_VISIBLE_DEVICES"] = (os.environ.get("HIP_VISIBLE_DEVICES") or "0").split(",")[0]
-            best = 0.0
             reps = reps_of[name]
-            for _ in range(2):
+            rates = []
+            for _ in range(3):
                 r = subprocess.run([exe, path, "--threads", str(workers), "--repeat", str(reps)], capture_output=True,
                                    text=True, env=env, timeout=120)
                 if r.returncode != 0:
                     return dict(out, error=(r.stderr or "mtgpu_scan_file failed")[-300:])
                 j = json.loads(r.stdout)
-                best = max(best, n * reps / max(j["scan_work_us"] * 1e-6, 1e-9))
-            out[name + "_frames_per_s"] = best
+                rates.append(n * reps / max(j["scan_work_us"] * 1e-6, 1e-9))
+            rates.sort()
+            out[name + "_frames_per_s"] = rates[1]                    # the median of three runs
+            out[name + "_spread"] = {"median": rates[1], "min": rates[0], "max": rates[2], "runs": 3}
     out["speedup"] = out["compact8_zero_copy_frames_per_s"] / out["aos40_copy_frames_per_s"]
     # bytes that cross PCIe per frame: the staged records + offset + side-data byte in, one flag byte out
     recs = float(np.mean([len(f) for f in frames]))
@@ -391,23 +397,25 @@ def host_fed_leg(spec, mv, off):
     out["note"] = ("PCIe-inclusive: what a real decode pipeline gets per GPU; the link, not the kernel, is the limit "
                    "(the resident `value` is ~30x higher)")
     try:
-        out["config4_64_streams"] = host_fed_batch64(exe)
+        out["config4_64_streams"] = host_fed_batch64(exe, runs=runs, seconds=seconds)
     except Exception as e:      # informational
         out["config4_64_streams"] = {"error": repr(e)}
     return out
 
 
-def host_fed_batch64(exe, n=12, reps=600, extra_env=None, configs=((64, 1), (16, 4))):
+def host_fed_batch64(exe, n=12, reps=600, extra_env=None, configs=((64, 1), (16, 4)), runs=3, seconds=15.0):
     """BASELINE config 4 through the product-shaped path on ONE device: 64 distinct-seed 1080p dense8x8 streams
-    (12 distinct frames each, presented 600x = 7200 frames per stream, 460 800 per run: long enough for the
-    steady-state window to dwarf the staggered set-up) through process_batch of the C++ host layer at 64 streams
-    x 1 worker and 16 streams x 4 workers; default staging (compact, zero-copy)."""
+    (12 distinct frames each) through process_batch of the C++ host layer at 64 streams x 1 worker and 16 streams x 4
+    workers; default staging (compact, zero-copy).  Per shape: one short run (`reps` presentations of every stream —
+    a few seconds, in which creating the pipes and page-locking their staging is > 10 % of the wall: kept as
+    `cold_start`) and `runs` long ones of at least `seconds` each (set-up < 3 % of the wall), reported as
+    median / min / max.  The top-level figures of a shape are the medians of the long runs."""
     import tempfile
     import mvtrim_amd as m
     from mvtrim_amd import synth
     d = "/dev/shm" if os.path.isdir("/dev/shm") else None
-    res = {"source": f"64 distinct-seed {n}-frame 1080p dense8x8 streams, each repeated {reps}x "
-                     f"({64 * n * reps} frames per run), page-cache resident", "gpus": 1}
+    res = {"source": f"64 distinct-seed {n}-frame 1080p dense8x8 streams, page-cache resident; per shape a cold start "
+                     f"({reps} presentations of every stream) and {runs} runs of >= {seconds:.0f} s", "gpus": 1}
     with tempfile.TemporaryDirectory(dir=d) as tmp:
         paths = []
         for k in range(64):
@@ -423,22 +431,27 @@ def host_fed_batch64(exe, n=12, reps=600, extra_env=None, configs=((64, 1), (16,
             env.pop(k, None)
         env["HIP_VISIBLE_DEVICES"] = (os.environ.get("HIP_VISIBLE_DEVICES") or "0").split(",")[0]
         env.update(extra_env or {})
-        for streams, threads in configs:
+
+        def one(streams, threads, reps_):
             r = subprocess.run([exe] + paths + ["--streams", str(streams), "--threads", str(threads), "--repeat",
-                                                str(reps), "--summary", "--outdir", tmp], capture_output=True,
-                               text=True, env=env, timeout=300)
+                                                str(reps_), "--summary", "--outdir", tmp], capture_output=True,
+                               text=True, env=env, timeout=600)
             if r.returncode != 0:
-                res[f"{streams}x{threads}"] = {"error": (r.stderr or "mtgpu_scan_file failed")[-300:]}
-                continue
+                return {"error": (r.stderr or "mtgpu_scan_file failed")[-300:]}
             lines = [json.loads(ln) for ln in r.stdout.strip().splitlines()]
             s = [j["batch_summary"] for j in lines if "batch_summary" in j][0]
             jobs = [j for j in lines if "batch_summary" not in j]
             workers = streams * threads
             wall = max(s["wall_us"], 1) * 1e-6
             busy = max(s["decode_us"] + s["analyze_us"], 1)
-            res[f"{streams}x{threads}"] = {
-                "streams": streams, "workers_per_stream": threads, "frames": s["frames_scanned"], "jobs": s["jobs"],
-                "frames_per_s_wall": s["frames_scanned"] / wall,          # includes creating 64xT contexts + pinned pipes
+            setup_ms = {"mtgpu_create_total": s["held"].get("ctx_create_us", 0) / 1e3,
+                        "mtgpu_pipe_create_per_worker": s["held"].get("pipe_create_us", 0) / 1e3 / max(workers, 1),
+                        # page-locking incl. the batches pinned later, on first use (summed over the run / per worker)
+                        "page_locking_per_worker": s["held"].get("pin_us", 0) / 1e3 / max(workers, 1),
+                        "batches_pinned": s["held"].get("pinned_batches", 0)}
+            return {
+                "streams": streams, "workers_per_stream": threads, "repeat": reps_, "frames": s["frames_scanned"], "jobs": s["jobs"],
+                "frames_per_s_wall": s["frames_scanned"] / wall,          # includes creating the contexts + pinned pipes
                 # steady state: all frames over the window [first worker of any video ready, last result of any
                 # video] — pipes persist from video to video, so set-up happens before it and tear-down after it
                 "frames_per_s_steady": s["frames_scanned"] / max(s.get("scan_window_us", 0) * 1e-6, 1e-9)
@@ -447,6 +460,8 @@ def host_fed_batch64(exe, n=12, reps=600, extra_env=None, configs=((64, 1), (16,
                 "frames_per_s_sum_of_streams": (float(np.mean([j["frames_scanned"] / max(j["scan_work_us"] * 1e-6, 1e-9)
                                                                for j in jobs])) * streams) if jobs else None,
                 "wall_ms": s["wall_us"] / 1e3, "wall_ms_until_last_video": s.get("scan_wall_us", 0) / 1e3,
+                # share of the wall a worker spent creating its pipe and page-locking its staging
+                "setup_share_of_wall": (setup_ms["mtgpu_pipe_create_per_worker"] + setup_ms["page_locking_per_worker"]) / (wall * 1e3),
                 # CPU time of the whole process over the run (getrusage) / wall: how many CPUs it kept busy
                 "cpus_busy": {"user": s.get("cpu_user_us", 0) / max(s["wall_us"], 1), "sys": s.get("cpu_sys_us", 0) / max(s["wall_us"], 1)},
                 # CPU time the worker threads got / the wall time they spent copying + submitting (waiting sleeps):
@@ -455,11 +470,7 @@ def host_fed_batch64(exe, n=12, reps=600, extra_env=None, configs=((64, 1), (16,
                 "cpu_gate": {"tokens": s.get("gate_tokens", 0), "wait_share_of_worker_time": s.get("gate_wait_us", 0) / (workers * wall * 1e6)},
                 # CPUs next to the device that the worker threads are confined to (0 = not pinned: no CPU quota in force)
                 "cpu_window": {"cpus": s.get("cpu_window", 0), "first": s.get("cpu_window_first", -1)},
-                "setup_ms": {"mtgpu_create_total": s["held"].get("ctx_create_us", 0) / 1e3,
-                             "mtgpu_pipe_create_per_worker": s["held"].get("pipe_create_us", 0) / 1e3 / max(workers, 1),
-                             # page-locking incl. the batches pinned later, on first use (summed over the run / per worker)
-                             "page_locking_per_worker": s["held"].get("pin_us", 0) / 1e3 / max(workers, 1),
-                             "batches_pinned": s["held"].get("pinned_batches", 0)},
+                "setup_ms": setup_ms,
                 "worker_time_share": {"init": s["init_us"] / (workers * wall * 1e6),
                                       "reading_frames": s["decode_us"] / busy,
                                       "copy_out_to_pinned": s["copy_us"] / busy,
@@ -470,6 +481,29 @@ def host_fed_batch64(exe, n=12, reps=600, extra_env=None, configs=((64, 1), (16,
                                        "mem_pools": s["held"]["mem_pools"],
                                        "pinned_MiB": s["held"]["pinned_bytes"] / 2**20,
                                        "device_MiB": s["held"]["device_bytes"] / 2**20}}
+
+        for streams, threads in configs:
+            cold = one(streams, threads, reps)
+            if "error" in cold or runs <= 0:
+                res[f"{streams}x{threads}"] = cold if "error" in cold else dict(cold, cold_start=None, long_runs=0)
+                continue
+            # long runs: enough presentations for >= `seconds` of wall at the cold run's steady rate
+            rate = cold["frames_per_s_steady"] or cold["frames_per_s_wall"]
+            reps_long = max(reps, int(np.ceil(seconds * rate / (64 * n))))
+            longs = [one(streams, threads, reps_long) for _ in range(runs)]
+            bad = [x for x in longs if "error" in x]
+            if bad:
+                res[f"{streams}x{threads}"] = dict(bad[0], cold_start=cold)
+                continue
+            by_wall = sorted(longs, key=lambda x: x["frames_per_s_wall"])
+            mid = dict(by_wall[len(by_wall) // 2])                 # the median run, whole — its breakdown belongs to its rate
+            for key in ("frames_per_s_wall", "frames_per_s_steady"):
+                vals = sorted(x[key] for x in longs if x[key])
+                mid[key + "_spread"] = {"median": vals[len(vals) // 2], "min": vals[0], "max": vals[-1], "runs": len(vals)}
+                mid[key] = vals[len(vals) // 2]
+            mid["cold_start"] = {k_: cold[k_] for k_ in ("repeat", "frames", "frames_per_s_wall", "frames_per_s_steady", "wall_ms",
+                                                        "setup_share_of_wall", "setup_ms")}
+            res[f"{streams}x{threads}"] = mid
     return res
 
 
@@ -971,7 +1005,7 @@ def _run_rank(a):
             cpu = cpu_baseline(params, mv, off, tile_flags, a.cpu_seconds, a.workload)
         if world == 1 and not a.no_host and a.workload == "1080p_dense8x8":
             try:
-                host = host_fed_leg(spec, mv, off)
+                host = host_fed_leg(spec, mv, off, a.host_runs, a.host_seconds)
             except Exception as e:          # informational leg
                 host = {"error": repr(e)}
         if host and cpu and "error" not in host:

@@ -22,7 +22,7 @@ if os.environ.get("ONLY_DEFAULT") == "1":
 if os.environ.get("BATCH_AB") == "1":       # 4 vs 8 vs 16 MiB, twice, interleaved
     SETTINGS = tuple((f"{mb} MiB batches, pass {k}", {"MTGPU_BATCH_MB": str(mb)}) for k in (1, 2) for mb in (4, 8, 16))
 for name, env in SETTINGS:
-    r = bench.host_fed_batch64(exe, reps=int(os.environ.get("REPS", "250")), extra_env=env, configs=((64, 1), (16, 4), (4, 16)))
+    r = bench.host_fed_batch64(exe, reps=int(os.environ.get("REPS", "250")), extra_env=env, runs=0, configs=((64, 1), (16, 4), (4, 16)))
     out[name] = {k: {kk: vv for kk, vv in v.items() if kk in ("frames_per_s_wall", "frames_per_s_steady", "frames_per_s_sum_of_streams", "wall_ms", "wall_ms_until_last_video", "setup_ms",
                                                               "worker_time_share", "held_on_one_device")}
                  for k, v in r.items() if isinstance(v, dict)}

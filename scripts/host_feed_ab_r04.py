@@ -103,7 +103,7 @@ out = {}
 for p in range(int(os.environ.get("PASSES", "2"))):
     for name, env in SETTINGS.items():
         c0 = cpu_stat()
-        r = bench.host_fed_batch64(exe, reps=int(os.environ.get("REPS", "400")), extra_env=env, configs=configs)
+        r = bench.host_fed_batch64(exe, reps=int(os.environ.get("REPS", "400")), extra_env=env, runs=0, configs=configs)
         c1 = cpu_stat()
         throttle = {k: c1.get(k, 0) - c0.get(k, 0) for k in ("nr_periods", "nr_throttled", "throttled_usec")}
         keep = {k: {kk: vv for kk, vv in v.items() if kk in ("frames_per_s_wall", "frames_per_s_steady", "wall_ms", "setup_ms",

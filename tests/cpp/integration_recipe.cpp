@@ -22,7 +22,7 @@ class MotionScanner {
   int in_flight_ = 0;
 
   bool collect_one(std::vector<double> &ts) {
-    mtgpu_batch *done; const uint8_t *flags; const double *pts; uint32_t n;
+    mtgpu_batch *done = nullptr; const uint8_t *flags; const double *pts; uint32_t n;
     --in_flight_;
     if (mtgpu_pipe_collect(pipe_, &done, &flags, &pts, nullptr, &n) != MT_OK) {
       LOG_ERROR("mtgpu: {}", mtgpu_last_error());
@@ -65,11 +65,18 @@ class MotionScanner {
     }
     return true;
   }
-  // where scan_range returns `ts`
-  void finish(std::vector<double> &ts) {
-    if (batch_ && mtgpu_pipe_submit(pipe_, batch_) == MT_OK) ++in_flight_;
-    batch_ = nullptr;
-    while (in_flight_ > 0 && collect_one(ts)) {}
+  // where scan_range returns `ts`: false = a batch was lost (the caller fails the chunk, as scan_range's callers do
+  // when initialize() fails) — never a silently shorter `ts`
+  bool finish(std::vector<double> &ts) {
+    bool ok = true;
+    if (batch_) {
+      if (mtgpu_pipe_submit(pipe_, batch_) == MT_OK) ++in_flight_;
+      else { LOG_ERROR("mtgpu: {}", mtgpu_last_error()); mtgpu_pipe_release(pipe_, batch_); ok = false; }   // a failed submit leaves the batch ours
+      batch_ = nullptr;
+    }
+    while (in_flight_ > 0)
+      if (!collect_one(ts)) ok = false;          // keep draining: every batch in flight is collected and released
+    return ok;
   }
   ~MotionScanner() { mtgpu_pipe_destroy(pipe_); mtgpu_destroy(gpu_); }
 };
@@ -96,7 +103,7 @@ int main() {
     const bool has_sd = f % 15 != 0;                              // every 15th frame: no MV side data at all
     if (!s.on_frame(has_sd ? &sd : nullptr, f / 30.0, ts)) return 1;
   }
-  s.finish(ts);
+  if (!s.finish(ts)) return 1;
   std::printf("motion %zu first %.6f last %.6f\n", ts.size(), ts.empty() ? -1.0 : ts.front(), ts.empty() ? -1.0 : ts.back());
   return 0;
 }
