@@ -76,7 +76,9 @@ def parse(argv=None):
     ap.add_argument("--no-host", action="store_true", help="skip the host-fed (PCIe-inclusive) leg")
     ap.add_argument("--host-runs", type=int, default=3,
                     help="host-fed config-4 shapes: long runs per shape (median / min / max are reported; 0 = the short cold-start run only)")
-    ap.add_argument("--host-seconds", type=float, default=15.0, help="... and the least wall time of each long run")
+    ap.add_argument("--host-seconds", type=float, default=21.0,
+                    help="... and the least wall time of each long run (creating a worker's pipe and page-locking its staging "
+                         "takes ~0.6 s: under 3 %% of 21 s)")
     ap.add_argument("--no-pmc", action="store_true",
                     help="do not measure roofline.traffic with rocprofv3 child runs (N = 1 only; the committed figure is replayed)")
     ap.add_argument("--pmc-child", action="store_true",
@@ -345,7 +347,7 @@ def time_compact(w, steps, warmup=3):
     return pr["scan_ms"], pr["plan_ms"], flags.cpu().numpy()
 
 
-def host_fed_leg(spec, mv, off, runs=3, seconds=15.0):
+def host_fed_leg(spec, mv, off, runs=3, seconds=21.0):
     """PCIe-inclusive rate of the host dispatcher (never `value`): the C++ front end mtgpu_scan_file
     fed by 16 worker threads from a 12-frame stream of the headline workload presented many times (MV
     bytes cache-resident, as when a decoder thread has just written them), with the default
@@ -403,12 +405,12 @@ def host_fed_leg(spec, mv, off, runs=3, seconds=15.0):
     return out
 
 
-def host_fed_batch64(exe, n=12, reps=600, extra_env=None, configs=((64, 1), (16, 4)), runs=3, seconds=15.0):
+def host_fed_batch64(exe, n=12, reps=600, extra_env=None, configs=((64, 1), (16, 4)), runs=3, seconds=21.0):
     """BASELINE config 4 through the product-shaped path on ONE device: 64 distinct-seed 1080p dense8x8 streams
     (12 distinct frames each) through process_batch of the C++ host layer at 64 streams x 1 worker and 16 streams x 4
     workers; default staging (compact, zero-copy).  Per shape: one short run (`reps` presentations of every stream —
     a few seconds, in which creating the pipes and page-locking their staging is > 10 % of the wall: kept as
-    `cold_start`) and `runs` long ones of at least `seconds` each (set-up < 3 % of the wall), reported as
+    `cold_start`) and `runs` long ones of at least `seconds` each (21 s: set-up < 3 % of the wall), reported as
     median / min / max.  The top-level figures of a shape are the medians of the long runs."""
     import tempfile
     import mvtrim_amd as m
@@ -489,7 +491,8 @@ def host_fed_batch64(exe, n=12, reps=600, extra_env=None, configs=((64, 1), (16,
                 continue
             # long runs: enough presentations for >= `seconds` of wall at the cold run's steady rate
             rate = cold["frames_per_s_steady"] or cold["frames_per_s_wall"]
-            reps_long = max(reps, int(np.ceil(seconds * rate / (64 * n))))
+            # (a warm run is ~10 % faster than the cold one the rate comes from)
+            reps_long = max(reps, int(np.ceil(1.12 * seconds * rate / (64 * n))))
             longs = [one(streams, threads, reps_long) for _ in range(runs)]
             bad = [x for x in longs if "error" in x]
             if bad:
@@ -509,7 +512,7 @@ def host_fed_batch64(exe, n=12, reps=600, extra_env=None, configs=((64, 1), (16,
 
 def replayed_traffic(workload, params_name, frames):
     """(HBM bytes per launch, where the number comes from) for a bench leg, from the committed summary of the
-    builder's own rocprofv3 --pmc passes (scripts/profile_r03.sh) — replayed, never measured by this run."""
+    builder's own rocprofv3 --pmc passes (scripts/profile_round.sh) — replayed, never measured by this run."""
     tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         rec = json.load(open(tp)).get(f"{workload}:{params_name}:{frames}")

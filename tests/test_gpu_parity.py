@@ -427,10 +427,11 @@ def test_scan_batch_properties_full_size(gpu_scanner_factory, grid, cfg):
     assert np.array_equal(s.check_frames(m.FrameBatch(b.mv, b.frame_off)), want[order])
 
 
-@pytest.mark.parametrize("n_frames", [1, 63, 1024, 1025, 5000, 32768, 32769, 70001])
+@pytest.mark.parametrize("n_frames", [1, 63, 1024, 1025, 5000, 32768, 32769, 70001, 1100003])
 def test_work_list_every_plan_size(gpu_scanner_factory, n_frames):
     """The planning kernels at every size class: one block (<= 1024 frames), the fused form (<= 32 blocks: every block
-    counts the frames before it again), the two-kernel form beyond — tiny frames (0..3 records, a third of them without
+    counts the frames before it again), the two-kernel form beyond, and more than 1024 x 1024 frames (every planning
+    block then walks several times 1024 frames) — tiny frames (0..3 records, a third of them without
     side data, some with EMPTY side data), so that the oracle checks every one of up to 70 001 flags.  VECTORS_NEEDED 0
     makes the three kinds of frames differ: no side data -> false, empty side data -> true (every cell is active),
     records -> true."""
