@@ -467,26 +467,42 @@ struct NextStep {
   bool have;
 };
 
-// One work item (a frame of the work list, or a slice of one) by one workgroup.  `has_next`: the same workgroup scans
-// item + 1 (the next frame of the list) right after this one.  Returns false when the list has ended (every later
-// item is past its end too).
+// An entry of the work list with ONE 32-byte load — r0, r1 and f arrive together (read field by field the compiler
+// fetches f first, tests it, and only then asks for r0 / r1: two memory round trips at the start of every workgroup's
+// life instead of one; the list was just written by another kernel, so the first touch of a line comes from beyond
+// this XCD's L2).  The address is workgroup-uniform: a scalar load.
+__device__ __forceinline__ WorkItem load_item(const WorkItem *__restrict__ work, unsigned int wi) {
+  typedef unsigned int u32x8 __attribute__((ext_vector_type(8)));
+  const u32x8 raw = *reinterpret_cast<const u32x8 *>(work + wi);
+  WorkItem it;
+  it.r0 = (unsigned long long)raw[0] | ((unsigned long long)raw[1] << 32);
+  it.r1 = (unsigned long long)raw[2] | ((unsigned long long)raw[3] << 32);
+  it.f = raw[4];
+  it.pad[0] = it.pad[1] = it.pad[2] = 0u;
+  return it;
+}
+
+// item -> entry of the work list: bands and slices are never both > 1, and one slice per frame is the common case
+template <bool SPILL>
+__device__ __forceinline__ unsigned int item_entry(unsigned int item, int slices) {
+  return (SPILL || slices == 1) ? item : item / (unsigned int)slices;
+}
+
+// One work item (the list entry `me`, or a slice of it) by one workgroup.  `has_next`: the same workgroup scans
+// item + 1 (the list entry `nx`, asked for when this item began) right after this one.  Frames without side data (:219-221) never get here:
+// plan_scatter_kernel has answered them.
 template <int BLOCK, int UNROLL, int FB, int MODE, int VAR, int REC, bool SPILL>
-__device__ __forceinline__ bool scan_item(
-    const unsigned char *__restrict__ mv, const WorkItem *__restrict__ work,
+__device__ __forceinline__ void scan_item(
+    const unsigned char *__restrict__ mv, const WorkItem me, const WorkItem nx,
     const unsigned int item, const ScanK &k, unsigned char *__restrict__ flags,
     unsigned int *spill_q, unsigned int *slice_ws, unsigned int *tickets, unsigned int *lds,
     NextStep<UNROLL> &ns, const bool has_next) {
   typedef typename RawOf<REC>::type Raw;
   const int tid = threadIdx.x;
-  // item -> list entry, or (list entry, slice): bands and slices are never both > 1
   PT_DECL;
-  const unsigned int wi = SPILL ? item : item / (unsigned int)k.slices;
-  const int slice = SPILL ? 0 : (int)(item - wi * (unsigned int)k.slices);
-  // the frame: one 32-byte entry of the work list (workgroup-uniform address: a scalar load).  Frames without side
-  // data (:219-221) never get here: plan_scatter_kernel has answered them.
-  const WorkItem me = work[wi];
+  const unsigned int wi = item_entry<SPILL>(item, k.slices);
+  const int slice = (SPILL || k.slices == 1) ? 0 : (int)(item - wi * (unsigned int)k.slices);
   const unsigned int f = me.f;
-  if (f == kNoFrame) return false;
   // A pre-issued step is consumed only by the frame it was loaded for: whatever early-out a frame takes
   // between here and its streaming loop, a step that was not consumed can never leak its votes into a LATER frame.
   if (ns.have && ns.frame != f) ns.have = false;
@@ -665,8 +681,7 @@ __device__ __forceinline__ bool scan_item(
       }
       if constexpr (REC == 8 && !SPILL) {
         if (has_next && k.slices == 1 && k.vec_need != 0u && trows > 0) {   // exactly when the next frame's phase 1 runs
-          // next frame of the list (the list always ends in a kNoFrame entry): same pair alignment as above
-          const WorkItem nx = work[wi + 1u];
+          // next frame of the list (`nx`; the list always ends in a kNoFrame entry): same pair alignment as above
           const unsigned long long a = nx.r0, b = nx.r1;
           const bool sdn = nx.f != kNoFrame;
           const unsigned char *nb = mv + a * 8ull;
@@ -763,7 +778,7 @@ __device__ __forceinline__ bool scan_item(
       if (tid == 0)
         *ticket = __hip_atomic_fetch_add(&tickets[f], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __syncthreads();
-      if (*ticket != (unsigned int)(k.slices - 1)) { PT_ADD(3); PT_FLUSH(); return true; }   // not the last: done
+      if (*ticket != (unsigned int)(k.slices - 1)) { PT_ADD(3); PT_FLUSH(); return; }   // not the last: done
       if (tid == 0) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -875,7 +890,6 @@ __device__ __forceinline__ bool scan_item(
 
   if (tid == 0) store_flag(flags, f, (*total >= k.clust_need) ? 1 : 0, k.sys_flags);
   PT_FLUSH();
-  return true;
 }
 
 // Grid: one workgroup per k.group consecutive items of the work list.  Small frames (below ~128 KB: a few
@@ -913,22 +927,33 @@ __global__ __launch_bounds__(BLOCK) void scan_frames_kernel(
         for (int g = 0; g < k.group; ++g) {
           const unsigned int item = first + (unsigned int)g;
           if (item >= n_items) return;
-          const bool has_next = (g + 1 < k.group) && (item + 1u < n_items) && k.prefetch;
-          if (!scan_item<BLOCK, UNROLL, FB, MODE, VAR, REC, SPILL>(mv, work, item, k, flags, spill_q, slice_ws, tickets, lds, ns, has_next))
-            return;
+          const WorkItem me = load_item(work, item_entry<SPILL>(item, k.slices));
+          if (me.f == kNoFrame) return;              // the list has ended: every later item is past its end too
+          const bool more = (g + 1 < k.group) && (item + 1u < n_items);
+          const WorkItem nx = load_item(work, item_entry<SPILL>(more ? item + 1u : item, k.slices));
+          scan_item<BLOCK, UNROLL, FB, MODE, VAR, REC, SPILL>(mv, me, nx, item, k, flags, spill_q, slice_ws, tickets, lds, ns,
+                                                               more && k.prefetch);
         }
       }
     }
   }
   const unsigned int first = item0 + blockIdx.x * (unsigned int)k.group;
+  if (first >= n_items) return;
+  // the first entry is asked for before anything else is set up: its latency overlaps the kernel's scalar prologue
+  WorkItem me = load_item(work, item_entry<SPILL>(first, k.slices));
   for (int g = 0; g < k.group; ++g) {
     const unsigned int item = first + (unsigned int)g;
-    if (item >= n_items) break;
+    if (item >= n_items || me.f == kNoFrame) break;  // kNoFrame: the list has ended, every later item is past its end too
+    // the NEXT entry of this workgroup is asked for now (a scalar load: it completes while this item is scanned), so
+    // that a workgroup that scans several small frames pays the list's latency once, not once per frame
+    const bool more = (g + 1 < k.group) && (item + 1u < n_items);
+    WorkItem nx = me;
+    if (more) nx = load_item(work, item_entry<SPILL>(item + 1u, k.slices));
     // (no barrier between items: every LDS read of an item precedes its last barrier, and the
     //  next item's writes start with its own zeroing)
-    const bool has_next = (g + 1 < k.group) && (item + 1u < n_items) && k.prefetch;
-    if (!scan_item<BLOCK, UNROLL, FB, MODE, VAR, REC, SPILL>(mv, work, item, k, flags, spill_q, slice_ws, tickets, lds, ns, has_next))
-      break;
+    scan_item<BLOCK, UNROLL, FB, MODE, VAR, REC, SPILL>(mv, me, nx, item, k, flags, spill_q, slice_ws, tickets, lds, ns,
+                                                         more && k.prefetch);
+    me = nx;
   }
 }
 
