@@ -288,6 +288,7 @@ int make_plan(mtgpu_ctx *c, int lds_max, int cu_count) {
   }
   k.slices = 1;
   k.group = 1;
+  k.planned = 1;
   k.sys_flags = 0;                                            // per launch: launch_scan_on
   k.resident = std::min(std::max(exp_int("MTGPU_RESIDENT", 0), 0), 16);   // experiments: ticketed resident workgroups per CU
   k.align_lines = exp_int("MTGPU_ALIGN", 1) != 0 ? 1 : 0;     // experiments: 0 = streams start wherever the frame starts
@@ -402,6 +403,10 @@ int launch_scan_on(mtgpu_ctx *c, const void *d_mv, uint64_t n_records, const uin
   L.k.sys_flags = flags_sys;
   L.k.slices = choose_slices(c, n_records - rebase, n_frames);
   L.k.group = choose_group(c, n_records - rebase, n_frames, rec_bytes, L.k.slices);
+  // One frame per workgroup: the work list (frames without side data never get a workgroup).  Several small frames per
+  // workgroup: consecutive frames, looked up by the workgroup itself — such a workgroup is without work only if ALL its
+  // frames lack side data, and planning 10^5 frames would cost more than it saves (scan_kernels.hip, get_item).
+  L.k.planned = L.k.group == 1 ? 1 : 0;
   if ((uint64_t)n_frames * (uint64_t)L.k.slices >= (1ull << 32))
     return fail(MT_ERR_INVALID, "%u frames x %d slices: work items must stay below 2^32 per call", n_frames, L.k.slices);
   L.block = c->plan.block_threads;
@@ -417,7 +422,8 @@ int launch_scan_on(mtgpu_ctx *c, const void *d_mv, uint64_t n_records, const uin
   if (c->min_lds_kb > 0) L.lds_bytes = std::max(L.lds_bytes, std::min(c->min_lds_kb * 1024, c->lds_max));
   L.stream = st;
   // launch scratch, one stream-ordered block: [work list + planning counts | spill queue or slice tiles + tickets]
-  const size_t plan_bytes = (mtgpu::plan_scratch_bytes(n_frames) + 255u) & ~(size_t)255u;
+  const bool needs_plan = L.k.planned || (mtgpu::kExperiments && L.k.resident > 0);
+  const size_t plan_bytes = needs_plan ? ((mtgpu::plan_scratch_bytes(n_frames) + 255u) & ~(size_t)255u) : 0u;
   size_t bytes = plan_bytes;
   if (L.k.bands > 1) bytes += sizeof(unsigned int) * ((size_t)(n_records - rebase) + 4);   // spill queue: a slot per record
   if (L.k.slices > 1)
@@ -430,11 +436,11 @@ int launch_scan_on(mtgpu_ctx *c, const void *d_mv, uint64_t n_records, const uin
   if (exp_cache) {
     if (exp_cached_bytes < bytes) { (void)hipMalloc(&exp_cached, bytes * 2); exp_cached_bytes = bytes * 2; }
     scratch = exp_cached;
-  } else {
+  } else if (bytes) {
     e = scratch_alloc(c, &scratch, bytes, st);
   }
   if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(scan scratch)");
-  L.plan_ws = scratch;
+  L.plan_ws = needs_plan ? scratch : nullptr;
   unsigned int *rest = reinterpret_cast<unsigned int *>(static_cast<unsigned char *>(scratch) + plan_bytes);
   if (L.k.bands > 1) L.spill_q = rest;
   if (L.k.slices > 1) {
@@ -461,7 +467,7 @@ int launch_scan_on(mtgpu_ctx *c, const void *d_mv, uint64_t n_records, const uin
     e = mtgpu::launch_scan(L);
   }
   if (e != hipSuccess) rc = hip_fail(e, "scan launch");
-  if (exp_cache) return rc;
+  if (exp_cache || !scratch) return rc;
   hipError_t e2 = hipFreeAsync(scratch, st);
   if (rc == MT_OK && e2 != hipSuccess) rc = hip_fail(e2, "hipFreeAsync");
   return rc;

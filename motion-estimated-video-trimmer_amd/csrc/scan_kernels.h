@@ -28,6 +28,8 @@ struct ScanK {
   int group;               // consecutive work items per workgroup (>= 1; > 1 only with slices == 1)
   int align_lines;         // 40-byte records: peel < 16 head records so that the stream starts on a 128-byte line
   int prefetch;            // compact records, group > 1: issue the next frame's first step before this frame's cluster test
+  int planned;             // 1: work items are entries of the work list (one frame per workgroup; planning kernels ahead of the scan);
+                           // 0: WINDOW form — a workgroup owns `group` >= 2 consecutive frames and looks them up itself
   int resident;            // experiments build only: > 0 = that many resident workgroups per CU pull work items with tickets
                            // (one agent-scope atomic per k.group items) instead of one workgroup per k.group items
   int sys_flags;           // flags do not live in device memory (pinned host memory: the pipe's zero-copy staging, a caller's

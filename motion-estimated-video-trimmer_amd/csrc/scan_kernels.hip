@@ -467,6 +467,18 @@ struct NextStep {
   bool have;
 };
 
+// Does frame f have MV side data, and which records are its own — the offsets clamped to the batch as the planning
+// kernels and the window form of the scan both need them.  has_sd == NULL: a frame has side data iff it has records.
+__device__ __forceinline__ bool plan_frame(const unsigned long long *__restrict__ frame_off, const unsigned char *__restrict__ has_sd,
+                                           unsigned long long n_records, unsigned long long f, unsigned long long &r0,
+                                           unsigned long long &r1) {
+  r0 = frame_off[f];
+  r1 = frame_off[f + 1];
+  r1 = r1 < n_records ? r1 : n_records;
+  r0 = r0 < r1 ? r0 : r1;
+  return has_sd ? (has_sd[f] != 0) : (r1 > r0);
+}
+
 // An entry of the work list with ONE 32-byte load — r0, r1 and f arrive together (read field by field the compiler
 // fetches f first, tests it, and only then asks for r0 / r1: two memory round trips at the start of every workgroup's
 // life instead of one; the list was just written by another kernel, so the first touch of a line comes from beyond
@@ -486,6 +498,30 @@ __device__ __forceinline__ WorkItem load_item(const WorkItem *__restrict__ work,
 template <bool SPILL>
 __device__ __forceinline__ unsigned int item_entry(unsigned int item, int slices) {
   return (SPILL || slices == 1) ? item : item / (unsigned int)slices;
+}
+
+// Work item -> frame.  k.planned: an entry of the work list (one frame per workgroup: frames without side data have been
+// answered by the planning kernels and are not in the list).  Otherwise the WINDOW form — a workgroup owns k.group >= 2
+// consecutive frames of the batch and looks them up itself; it is without work only if ALL of them lack side data, so
+// no period of key frames leaves an XCD idle, and the launch needs no planning kernels (small frames: tens of
+// thousands of workgroups per launch, where planning and the surplus workgroups cost 1.7 %).  kNoFrame there means
+// "this frame has no side data" (:219-221), not "the list has ended".
+// (frame_off / has_sd are kernel parameters of their own, `const ... __restrict__`: inside a struct they would lose
+//  that, and the compiler would fetch them with per-lane vector loads ordered against the kernel's stores instead of
+//  scalar loads — measured: the window form 2 % slower than round 5's, 11 % with a key frame every 2 frames)
+template <bool SPILL>
+__device__ __forceinline__ WorkItem get_item(const ScanK &k, const WorkItem *__restrict__ work,
+                                             const unsigned long long *__restrict__ frame_off, const unsigned char *__restrict__ has_sd,
+                                             unsigned long long n_records, unsigned long long rebase, unsigned int item) {
+  if (k.planned) return load_item(work, item_entry<SPILL>(item, k.slices));
+  WorkItem it;
+  unsigned long long r0, r1;
+  const bool sd = plan_frame(frame_off, has_sd, n_records, item, r0, r1);
+  it.r0 = r0 > rebase ? r0 - rebase : 0ull;
+  it.r1 = r1 > rebase ? r1 - rebase : 0ull;
+  it.f = sd ? item : kNoFrame;
+  it.pad[0] = it.pad[1] = it.pad[2] = 0u;
+  return it;
 }
 
 // One work item (the list entry `me`, or a slice of it) by one workgroup.  `has_next`: the same workgroup scans
@@ -902,58 +938,59 @@ __device__ __forceinline__ void scan_item(
 template <int BLOCK, int UNROLL, int FB, int MODE, int VAR, int REC, bool SPILL>
 __global__ __launch_bounds__(BLOCK) void scan_frames_kernel(
     const unsigned char *__restrict__ mv, const WorkItem *__restrict__ work,
-    unsigned int item0, unsigned int n_items, ScanK k, unsigned char *__restrict__ flags,
+    const unsigned long long *__restrict__ frame_off, const unsigned char *__restrict__ has_sd, unsigned long long n_records,
+    unsigned long long rebase, unsigned int item0, unsigned int n_items, ScanK k, unsigned char *__restrict__ flags,
     unsigned int *spill_q, unsigned int *slice_ws, unsigned int *tickets, unsigned int *next_ticket) {
   extern __shared__ __attribute__((aligned(16))) unsigned int lds[];
   NextStep<UNROLL> ns;
   ns.have = false;
   ns.frame = 0u;
-  if constexpr (kExperiments) {
-    if (k.resident > 0) {
+  unsigned int first = item0 + blockIdx.x * (unsigned int)k.group;
+  unsigned int nextv = 0u;
+  unsigned int *slot = lds + (k.cnt_words + 2 * k.mask_rows * k.W + 4);       // (resident form: one word past the kernel's own LDS use)
+  const bool resident = kExperiments && k.resident > 0;
+  if (resident && threadIdx.x == 0)
+    nextv = __hip_atomic_fetch_add(next_ticket, (unsigned int)k.group, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (;;) {
+    if (resident) {
       // A/B form (experiments build, MTGPU_RESIDENT = workgroups per CU): a fixed grid of workgroups pulls k.group
       // items at a time with one agent-scope atomic; the next ticket is on its way while the current items are
       // scanned.  The loop ends for every workgroup: tickets only grow, and the first one at or past n_items (or
-      // the first kNoFrame entry) is the last this workgroup takes.
-      unsigned int *slot = lds + (k.cnt_words + 2 * k.mask_rows * k.W + 4);     // one word past the kernel's own LDS use
-      unsigned int nextv = 0u;
-      if (threadIdx.x == 0) nextv = __hip_atomic_fetch_add(next_ticket, (unsigned int)k.group, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      for (;;) {
-        __syncthreads();
-        if (threadIdx.x == 0) *slot = nextv;
-        __syncthreads();
-        const unsigned int first = *slot;
-        if (first >= n_items) return;
-        if (threadIdx.x == 0) nextv = __hip_atomic_fetch_add(next_ticket, (unsigned int)k.group, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (int g = 0; g < k.group; ++g) {
-          const unsigned int item = first + (unsigned int)g;
-          if (item >= n_items) return;
-          const WorkItem me = load_item(work, item_entry<SPILL>(item, k.slices));
-          if (me.f == kNoFrame) return;              // the list has ended: every later item is past its end too
-          const bool more = (g + 1 < k.group) && (item + 1u < n_items);
-          const WorkItem nx = load_item(work, item_entry<SPILL>(more ? item + 1u : item, k.slices));
-          scan_item<BLOCK, UNROLL, FB, MODE, VAR, REC, SPILL>(mv, me, nx, item, k, flags, spill_q, slice_ws, tickets, lds, ns,
-                                                               more && k.prefetch);
-        }
-      }
+      // the end of the list) is the last this workgroup takes.
+      __syncthreads();
+      if (threadIdx.x == 0) *slot = nextv;
+      __syncthreads();
+      first = *slot;
+      if (first < n_items && threadIdx.x == 0)
+        nextv = __hip_atomic_fetch_add(next_ticket, (unsigned int)k.group, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-  }
-  const unsigned int first = item0 + blockIdx.x * (unsigned int)k.group;
-  if (first >= n_items) return;
-  // the first entry is asked for before anything else is set up: its latency overlaps the kernel's scalar prologue
-  WorkItem me = load_item(work, item_entry<SPILL>(first, k.slices));
-  for (int g = 0; g < k.group; ++g) {
-    const unsigned int item = first + (unsigned int)g;
-    if (item >= n_items || me.f == kNoFrame) break;  // kNoFrame: the list has ended, every later item is past its end too
-    // the NEXT entry of this workgroup is asked for now (a scalar load: it completes while this item is scanned), so
-    // that a workgroup that scans several small frames pays the list's latency once, not once per frame
-    const bool more = (g + 1 < k.group) && (item + 1u < n_items);
-    WorkItem nx = me;
-    if (more) nx = load_item(work, item_entry<SPILL>(item + 1u, k.slices));
-    // (no barrier between items: every LDS read of an item precedes its last barrier, and the
-    //  next item's writes start with its own zeroing)
-    scan_item<BLOCK, UNROLL, FB, MODE, VAR, REC, SPILL>(mv, me, nx, item, k, flags, spill_q, slice_ws, tickets, lds, ns,
-                                                         more && k.prefetch);
-    me = nx;
+    if (first >= n_items) return;
+    // the first frame is asked for before anything else is set up: its latency overlaps the kernel's scalar prologue
+    WorkItem me = get_item<SPILL>(k, work, frame_off, has_sd, n_records, rebase, first);
+    bool ended = false;
+    for (int g = 0; g < k.group; ++g) {
+      const unsigned int item = first + (unsigned int)g;
+      if (item >= n_items) break;
+      // the NEXT frame of this workgroup is asked for now (scalar loads: they complete while this frame is scanned),
+      // so that a workgroup that scans several small frames pays that latency once, not once per frame
+      const bool more = (g + 1 < k.group) && (item + 1u < n_items);
+      WorkItem nx = me;
+      if (more) nx = get_item<SPILL>(k, work, frame_off, has_sd, n_records, rebase, item + 1u);
+      if (me.f != kNoFrame) {
+        // (no barrier between items: every LDS read of an item precedes its last barrier, and the
+        //  next item's writes start with its own zeroing)
+        scan_item<BLOCK, UNROLL, FB, MODE, VAR, REC, SPILL>(mv, me, nx, item, k, flags, spill_q, slice_ws, tickets, lds, ns,
+                                                             more && k.prefetch);
+      } else if (k.planned) {
+        ended = true;                            // the list has ended: every later item is past its end too
+        break;
+      } else {
+        if (threadIdx.x == 0) store_flag(flags, item, 0, k.sys_flags);          // :219-221 — no side data: false
+        ns.have = false;
+      }
+      me = nx;
+    }
+    if (!resident || ended) return;
   }
 }
 
@@ -973,16 +1010,6 @@ __global__ __launch_bounds__(BLOCK) void scan_frames_kernel(
 //                                             at most 1024 of them
 // has_sd == NULL: a frame has side data iff it has records; has_sd[f] != 0 with no records is a frame whose side data
 // is empty: it reaches the scan, which then runs the cluster test on an all-zero grid (vectors_needed == 0 matters).
-__device__ __forceinline__ bool plan_frame(const unsigned long long *__restrict__ frame_off, const unsigned char *__restrict__ has_sd,
-                                           unsigned long long n_records, unsigned long long f, unsigned long long &r0,
-                                           unsigned long long &r1) {
-  r0 = frame_off[f];
-  r1 = frame_off[f + 1];
-  r1 = r1 < n_records ? r1 : n_records;
-  r0 = r0 < r1 ? r0 : r1;
-  return has_sd ? (has_sd[f] != 0) : (r1 > r0);
-}
-
 __global__ __launch_bounds__(kPlanBlock) void plan_count_kernel(
     const unsigned long long *__restrict__ frame_off, const unsigned char *__restrict__ has_sd, unsigned long long n_records,
     unsigned int n_frames, unsigned int per, unsigned int *__restrict__ blk_cnt) {
@@ -1131,13 +1158,14 @@ static hipError_t launch_one(const ScanLaunch &L) {
   }
   const unsigned long long items = (unsigned long long)L.n_frames * (unsigned long long)(SPILL ? 1 : L.k.slices);
   const unsigned long long group = (unsigned long long)(L.k.group > 0 ? L.k.group : 1);
-  WorkItem *work = static_cast<WorkItem *>(L.plan_ws);
-  unsigned int *next_ticket = reinterpret_cast<unsigned int *>(work + (size_t)L.n_frames + 1u) + plan_blocks(L.n_frames);
+  WorkItem *work = static_cast<WorkItem *>(L.plan_ws);                         // nullptr in the window form (never read there)
+  unsigned int *next_ticket = work ? reinterpret_cast<unsigned int *>(work + (size_t)L.n_frames + 1u) + plan_blocks(L.n_frames) : nullptr;
   if (kExperiments && L.k.resident > 0) {
     const unsigned long long want = (unsigned long long)(L.cu_count > 0 ? L.cu_count : 256) * (unsigned long long)L.k.resident;
     const unsigned long long wgs = (items + group - 1) / group;
     hipLaunchKernelGGL(kern, dim3((unsigned int)(wgs < want ? wgs : want)), dim3(BLOCK), L.lds_bytes + 16, L.stream, L.mv, work,
-                       0u, (unsigned int)items, L.k, L.flags, L.spill_q, L.slice_ws, L.tickets, next_ticket);
+                       L.frame_off, L.has_sd, L.n_records, L.rebase, 0u, (unsigned int)items, L.k, L.flags, L.spill_q, L.slice_ws,
+                       L.tickets, next_ticket);
     return hipGetLastError();
   }
   const unsigned long long chunk = L.item_chunk ? L.item_chunk : (1ull << 30);   // workgroups per launch: grid.x stays < 2^31
@@ -1145,8 +1173,8 @@ static hipError_t launch_one(const ScanLaunch &L) {
     const unsigned long long left = items - i0;
     const unsigned long long wgs = (left + group - 1) / group;
     const unsigned int n = (unsigned int)(wgs < chunk ? wgs : chunk);
-    hipLaunchKernelGGL(kern, dim3(n), dim3(BLOCK), L.lds_bytes, L.stream, L.mv, work, (unsigned int)i0,
-                       (unsigned int)items, L.k, L.flags, L.spill_q, L.slice_ws, L.tickets, next_ticket);
+    hipLaunchKernelGGL(kern, dim3(n), dim3(BLOCK), L.lds_bytes, L.stream, L.mv, work, L.frame_off, L.has_sd, L.n_records,
+                       L.rebase, (unsigned int)i0, (unsigned int)items, L.k, L.flags, L.spill_q, L.slice_ws, L.tickets, next_ticket);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
@@ -1222,14 +1250,18 @@ hipError_t launch_scan(const ScanLaunch &L) {
     e = hipMemsetAsync(L.tickets, 0, sizeof(unsigned int) * (size_t)L.n_frames, L.stream);
     if (e != hipSuccess) return e;
   }
-  if (!L.plan_ws || ((uintptr_t)L.plan_ws & 31u) != 0u || !L.frame_off || L.rebase > L.n_records) return hipErrorInvalidValue;
-  {
+  const bool needs_plan = L.k.planned || (kExperiments && L.k.resident > 0);
+  if (!L.frame_off || L.rebase > L.n_records) return hipErrorInvalidValue;
+  if (needs_plan && (!L.plan_ws || ((uintptr_t)L.plan_ws & 31u) != 0u)) return hipErrorInvalidValue;
+  if (!L.k.planned && (L.k.group < 2 || L.k.slices != 1)) return hipErrorInvalidValue;     // window form: several whole frames per workgroup
+  if (needs_plan) {
     WorkItem *work = static_cast<WorkItem *>(L.plan_ws);
     unsigned int *blk_cnt = reinterpret_cast<unsigned int *>(work + (size_t)L.n_frames + 1u);
     e = launch_plan(L, work, blk_cnt, blk_cnt + plan_blocks(L.n_frames));
     if (e != hipSuccess) return e;
-    if (L.ev_planned && (e = hipEventRecord(L.ev_planned, L.stream)) != hipSuccess) return e;
   }
+  // (profiling: the event between planning and scan — also in the window form, where nothing was planned)
+  if (L.ev_planned && (e = hipEventRecord(L.ev_planned, L.stream)) != hipSuccess) return e;
   switch (L.block) {
 #ifdef MTGPU_EXPERIMENTS
     case 256: e = launch_block<256>(L); break;

@@ -45,6 +45,29 @@ def test_product_library_does_not_link_the_oracle():
             assert "oracle" not in src.lower(), f"{f} mentions the oracle"
 
 
+def test_product_library_carries_no_calibration_code():
+    """bench.py's read-only calibration kernels live in a library of their own (csrc/calib -> libmtgpu_calib.so): the
+    product exports nothing named debug / calib, embeds no read_ceiling kernel, and neither it nor the Python package
+    refers to the calibration library; that library in turn exports exactly what csrc/calib/mtgpu_calib.h declares."""
+    import re
+    syms = subprocess.check_output(["nm", "-D", "--defined-only", _abi.LIB_PATH]).decode()
+    assert "debug" not in syms and "calib" not in syms
+    blob = open(_abi.LIB_PATH, "rb").read()
+    assert b"read_ceiling" not in blob and b"libmtgpu_calib" not in blob
+    assert b"plan_scatter_kernel" in blob and b"plan_count_kernel" in blob          # the work list's kernels are product
+    pkg = os.path.join(ROOT, "motion-estimated-video-trimmer_amd")
+    for f in os.listdir(pkg):
+        if f.endswith(".py"):
+            assert "calib" not in open(os.path.join(pkg, f)).read(), f
+    calib = os.path.join(pkg, "libmtgpu_calib.so")
+    assert os.path.exists(calib), "make -C csrc all builds it (bench.py loads it)"
+    hdr = open(os.path.join(pkg, "csrc", "calib", "mtgpu_calib.h")).read()
+    declared = sorted(set(re.findall(r"\b(mtcalib_\w+)\s*\(", hdr)))
+    exported = sorted(ln.split()[-1] for ln in subprocess.check_output(["nm", "-D", "--defined-only", calib]).decode().splitlines()
+                      if " T " in ln and "mtcalib_" in ln)
+    assert declared == exported == ["mtcalib_last_error", "mtcalib_read_ceiling"]
+
+
 def test_struct_layouts_match_header():
     assert C.sizeof(_abi.ScanParamsC) == 32 and _abi.ScanParamsC.grid_w.offset == 24
     assert _abi.ScanParamsC.vectors_needed.offset == 20 and _abi.ScanParamsC.mv_threshold_sq.offset == 0

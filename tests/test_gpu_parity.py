@@ -427,12 +427,15 @@ def test_scan_batch_properties_full_size(gpu_scanner_factory, grid, cfg):
     assert np.array_equal(s.check_frames(m.FrameBatch(b.mv, b.frame_off)), want[order])
 
 
+@pytest.mark.parametrize("group", ["1", ""])
 @pytest.mark.parametrize("n_frames", [1, 63, 1024, 1025, 5000, 32768, 32769, 70001, 1100003])
-def test_work_list_every_plan_size(gpu_scanner_factory, n_frames):
+def test_work_list_every_plan_size(gpu_scanner_factory, monkeypatch, n_frames, group):
     """The planning kernels at every size class: one block (<= 1024 frames), the fused form (<= 32 blocks: every block
     counts the frames before it again), the two-kernel form beyond, and more than 1024 x 1024 frames (every planning
-    block then walks several times 1024 frames) — tiny frames (0..3 records, a third of them without
-    side data, some with EMPTY side data), so that the oracle checks every one of up to 70 001 flags.  VECTORS_NEEDED 0
+    block then walks several times 1024 frames) — with MTGPU_GROUP=1 (one frame per workgroup: the work list at every
+    size) and with the automatic grouping (from 4096 frames on, these tiny frames go two to eight to a workgroup: the
+    WINDOW form, no planning kernels, the workgroup answers its own frames without side data).  Tiny frames (0..3
+    records, a third of them without side data, some with EMPTY side data), so that the oracle checks every flag.  VECTORS_NEEDED 0
     makes the three kinds of frames differ: no side data -> false, empty side data -> true (every cell is active),
     records -> true."""
     import torch
@@ -450,7 +453,10 @@ def test_work_list_every_plan_size(gpu_scanner_factory, n_frames):
         mv["dst_x"][three + q], mv["dst_y"][three + q], mv["src_x"][three + q], mv["src_y"][three + q] = gx * 16 + 8, 488, gx * 16, 488
     for vn, cn in ((0, 1), (1, 1)):
         p = ob.params_from_config(1920, 1080, vectors_needed=vn, clusters_needed=cn)
+        if group:
+            monkeypatch.setenv("MTGPU_GROUP", group)
         s = gpu_scanner_factory(p)
+        monkeypatch.delenv("MTGPU_GROUP", raising=False)
         want = ob.scan_frames(p, mv, off, has_sd, nthreads=8)
         got = s.check_frames(m.FrameBatch(mv, off, None, has_sd))
         bad = np.flatnonzero(want != got)
