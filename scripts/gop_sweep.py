@@ -60,7 +60,7 @@ def other_library(path, env=None):
 
 
 builds = [("new", m.MotionScanner(params, 0))]
-prev = os.path.join(ROOT, "scripts", "libmtgpu_prev.so")
+prev = os.environ.get("GOP_PREV_LIB") or os.path.join(ROOT, "scripts", "libmtgpu_prev.so")
 if os.path.exists(prev) and os.environ.get("GOP_PREV", "1") != "0":
     builds.append(("prev", other_library(prev)))
 exp = os.path.join(ROOT, "motion-estimated-video-trimmer_amd", "libmtgpu_experiments.so")
