@@ -174,12 +174,11 @@ int mtgpu_set_slices(mtgpu_ctx *ctx, int slices);
  *                AV_FRAME_DATA_MOTION_VECTORS side data (-> false, :219-221).
  *                NULL: a frame has side data iff it owns >= 1 record.
  *   d_flags      n_frames bytes (device): 1 = significant motion, 0 = none
- * Asynchronous on `stream`.  Large frames (one per workgroup): two or three launches — the planning kernels (frames
- * without side data are answered there and never get a workgroup: 4-14 us per call, measured as `plan_ms` by
- * mtgpu_profile_read), then the scan.  Small frames (several consecutive ones per workgroup): the scan alone.
- * What to expect: the rate does not depend on where the frames without records fall (key frame every 2 / 8 / 30
- * frames: within 0.3 % of none for large frames, 2 % for small ones, profiles/r06_gop_sweep_*.log,
- * r06_window_form_480p.log) nor on which HIP streams the process has used
+ * Asynchronous on `stream`: two or three launches — the planning kernels (frames without side data are answered
+ * there and never get a workgroup: 4-14 us per call, measured as `plan_ms` by mtgpu_profile_read), then the scan.
+ * What to expect: the rate does not depend on where the frames without records fall (key frame every 2 / 8 / 16 / 30
+ * frames: within 0.3 % of none for large frames, 1.6 % for 10^5 small ones, profiles/r06_gop_sweep_*.log,
+ * r06_staged_entries.log) nor on which HIP streams the process has used
  * before — through round 5 a launch on the default stream read 2 % faster once another stream of the process had run
  * a kernel, and only with a key frame every 30 frames (bench.py's state and workload): a single-stream caller now
  * gets the bench's rate (2952 us per call of the headline batch, single stream, against 2946 us in bench.py).

@@ -288,7 +288,6 @@ int make_plan(mtgpu_ctx *c, int lds_max, int cu_count) {
   }
   k.slices = 1;
   k.group = 1;
-  k.planned = 1;
   k.sys_flags = 0;                                            // per launch: launch_scan_on
   k.resident = std::min(std::max(exp_int("MTGPU_RESIDENT", 0), 0), 16);   // experiments: ticketed resident workgroups per CU
   k.align_lines = exp_int("MTGPU_ALIGN", 1) != 0 ? 1 : 0;     // experiments: 0 = streams start wherever the frame starts
@@ -354,6 +353,18 @@ int choose_group(const mtgpu_ctx *c, uint64_t n_records, uint32_t n_frames, int 
       if ((uint64_t)n_frames >= cus * 4ull) g = 4;
       else if ((uint64_t)n_frames >= cus * 2ull) g = 2;
     }
+    // Round 6, with the window form (a workgroup that owns several frames needs no work list and issues the next
+    // frame's first loads before this frame's cluster test): profiles/r06_group_ab.log, wall clock per call —
+    //   compact records on tiles that share a CU (1080p: 261 KB frames, 37 us per workgroup, of which ~3 us are
+    //   start-up): two frames per workgroup 635 -> 594 us at 16 384 frames, 174 -> 160 us at 4096 (four: 601 / 161);
+    //   40-byte records on a one-workgroup-per-CU tile (4K: 5.2 MB frames): 2895 -> 2881 us with two on equal frames,
+    //   but -3 % on ragged ones (profiles/r06_group_ab.log, second part: 10 MB work units leave a long tail) — not taken;
+    //   40-byte records on shared tiles (1080p 1.3 MB frames, 326 KB frames): nothing or a loss — they stay at one.
+    // Only where every workgroup slot of the chip is still filled twice over afterwards.
+    const uint64_t per_cu = c->plan.lds_bytes <= 40 * 1024 ? 4u : (c->plan.lds_bytes <= 80 * 1024 ? 2u : 1u);
+    if (g == 1 && c->k.bands == 1 && rec_bytes == MT_COMPACT_BYTES && c->k.prefetch && avg <= (2ull << 20) &&
+        (uint64_t)n_frames >= cus * per_cu * 4ull)
+      g = 2;
   }
   if (g > 64) g = 64;
   return g < 1 ? 1 : g;
@@ -403,10 +414,6 @@ int launch_scan_on(mtgpu_ctx *c, const void *d_mv, uint64_t n_records, const uin
   L.k.sys_flags = flags_sys;
   L.k.slices = choose_slices(c, n_records - rebase, n_frames);
   L.k.group = choose_group(c, n_records - rebase, n_frames, rec_bytes, L.k.slices);
-  // One frame per workgroup: the work list (frames without side data never get a workgroup).  Several small frames per
-  // workgroup: consecutive frames, looked up by the workgroup itself — such a workgroup is without work only if ALL its
-  // frames lack side data, and planning 10^5 frames would cost more than it saves (scan_kernels.hip, get_item).
-  L.k.planned = L.k.group == 1 ? 1 : 0;
   if ((uint64_t)n_frames * (uint64_t)L.k.slices >= (1ull << 32))
     return fail(MT_ERR_INVALID, "%u frames x %d slices: work items must stay below 2^32 per call", n_frames, L.k.slices);
   L.block = c->plan.block_threads;
@@ -419,11 +426,21 @@ int launch_scan_on(mtgpu_ctx *c, const void *d_mv, uint64_t n_records, const uin
     L.k.mask_rows = c->wide_chunk_rows + 2;
     L.lds_bytes = c->wide_lds_bytes;
   }
+  // several frames per workgroup: their list entries are parked in LDS behind the tile (scan_kernels.hip, stage_items)
+  L.k.stage_word = 0;
+  if (L.k.group > 1) {
+    const int at = (L.lds_bytes + 16 + 31) & ~31;             // (+16: the experiments build's ticket word sits right behind the tile)
+    if (at + mtgpu::kStageBytes <= c->lds_max) {
+      L.k.stage_word = at / 4;
+      L.lds_bytes = at + mtgpu::kStageBytes;
+    } else {
+      L.k.group = 1;                                          // a tile that fills LDS to the last 2 KB: one frame per workgroup
+    }
+  }
   if (c->min_lds_kb > 0) L.lds_bytes = std::max(L.lds_bytes, std::min(c->min_lds_kb * 1024, c->lds_max));
   L.stream = st;
   // launch scratch, one stream-ordered block: [work list + planning counts | spill queue or slice tiles + tickets]
-  const bool needs_plan = L.k.planned || (mtgpu::kExperiments && L.k.resident > 0);
-  const size_t plan_bytes = needs_plan ? ((mtgpu::plan_scratch_bytes(n_frames) + 255u) & ~(size_t)255u) : 0u;
+  const size_t plan_bytes = (mtgpu::plan_scratch_bytes(n_frames) + 255u) & ~(size_t)255u;
   size_t bytes = plan_bytes;
   if (L.k.bands > 1) bytes += sizeof(unsigned int) * ((size_t)(n_records - rebase) + 4);   // spill queue: a slot per record
   if (L.k.slices > 1)
@@ -436,11 +453,11 @@ int launch_scan_on(mtgpu_ctx *c, const void *d_mv, uint64_t n_records, const uin
   if (exp_cache) {
     if (exp_cached_bytes < bytes) { (void)hipMalloc(&exp_cached, bytes * 2); exp_cached_bytes = bytes * 2; }
     scratch = exp_cached;
-  } else if (bytes) {
+  } else {
     e = scratch_alloc(c, &scratch, bytes, st);
   }
   if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(scan scratch)");
-  L.plan_ws = needs_plan ? scratch : nullptr;
+  L.plan_ws = scratch;
   unsigned int *rest = reinterpret_cast<unsigned int *>(static_cast<unsigned char *>(scratch) + plan_bytes);
   if (L.k.bands > 1) L.spill_q = rest;
   if (L.k.slices > 1) {
@@ -467,7 +484,7 @@ int launch_scan_on(mtgpu_ctx *c, const void *d_mv, uint64_t n_records, const uin
     e = mtgpu::launch_scan(L);
   }
   if (e != hipSuccess) rc = hip_fail(e, "scan launch");
-  if (exp_cache || !scratch) return rc;
+  if (exp_cache) return rc;
   hipError_t e2 = hipFreeAsync(scratch, st);
   if (rc == MT_OK && e2 != hipSuccess) rc = hip_fail(e2, "hipFreeAsync");
   return rc;

@@ -26,10 +26,10 @@ struct ScanK {
   int cnt_words;           // LDS counter words per workgroup ((band_rows + 2) * gw fields, padded to 4)
   int mask_rows;           // chunk_rows + 2
   int group;               // consecutive work items per workgroup (>= 1; > 1 only with slices == 1)
+  int stage_word;          // group > 1: LDS word (32-byte aligned offset behind the tile) where the workgroup parks the list
+                           // entries of its 2nd .. group-th frame: 8 words each, kStageBytes in all
   int align_lines;         // 40-byte records: peel < 16 head records so that the stream starts on a 128-byte line
   int prefetch;            // compact records, group > 1: issue the next frame's first step before this frame's cluster test
-  int planned;             // 1: work items are entries of the work list (one frame per workgroup; planning kernels ahead of the scan);
-                           // 0: WINDOW form — a workgroup owns `group` >= 2 consecutive frames and looks them up itself
   int resident;            // experiments build only: > 0 = that many resident workgroups per CU pull work items with tickets
                            // (one agent-scope atomic per k.group items) instead of one workgroup per k.group items
   int sys_flags;           // flags do not live in device memory (pinned host memory: the pipe's zero-copy staging, a caller's
@@ -66,6 +66,8 @@ inline unsigned int plan_blocks(unsigned int n_frames) {
 inline size_t plan_scratch_bytes(unsigned int n_frames) {
   return sizeof(WorkItem) * ((size_t)n_frames + 1u) + sizeof(unsigned int) * ((size_t)plan_blocks(n_frames) + 4u);
 }
+
+constexpr int kStageBytes = 64 * 32;     // LDS behind the tile for the parked entries of a grouped workgroup (group <= 64)
 
 struct ScanLaunch {
   const unsigned char *mv;

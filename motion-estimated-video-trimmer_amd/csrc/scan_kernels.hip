@@ -467,8 +467,8 @@ struct NextStep {
   bool have;
 };
 
-// Does frame f have MV side data, and which records are its own — the offsets clamped to the batch as the planning
-// kernels and the window form of the scan both need them.  has_sd == NULL: a frame has side data iff it has records.
+// Does frame f have MV side data, and which records are its own (the offsets clamped to the batch).
+// has_sd == NULL: a frame has side data iff it has records.
 __device__ __forceinline__ bool plan_frame(const unsigned long long *__restrict__ frame_off, const unsigned char *__restrict__ has_sd,
                                            unsigned long long n_records, unsigned long long f, unsigned long long &r0,
                                            unsigned long long &r1) {
@@ -494,42 +494,49 @@ __device__ __forceinline__ WorkItem load_item(const WorkItem *__restrict__ work,
   return it;
 }
 
+// The entries a workgroup that owns several frames needs after its first: fetched by lanes 1 .. group-1 when the
+// workgroup starts (one memory latency for all of them, overlapped with the first entry's scalar load), parked in LDS
+// behind the tile, and read from there frame by frame.  Tiny frames (SD streams as compact records: 10 KB, about a
+// microsecond of streaming each) cannot hide a trip to memory per frame behind the previous frame — asked for one frame
+// ahead with scalar loads, 480p compact records ran at 1919 us per 262 144 frames against 1447 for round 5, whose
+// workgroups found their eight offsets in ONE cache line.
+// (kStageBytes of LDS behind the tile: 64 entries — choose_group never exceeds 64 frames per workgroup)
+__device__ __forceinline__ void stage_items(const WorkItem *__restrict__ work, unsigned int first, unsigned int n_items, int group,
+                                            unsigned int *stage) {
+  const unsigned int j = threadIdx.x;
+  if (j >= 1u && j < (unsigned int)group && first + j < n_items) {
+    const u32x4 *src = reinterpret_cast<const u32x4 *>(work + first + j);
+    const u32x4 a = src[0], b = src[1];
+    u32x4 *dst = reinterpret_cast<u32x4 *>(stage) + 2u * j;
+    dst[0] = a;
+    dst[1] = b;
+  }
+}
+__device__ __forceinline__ WorkItem staged_item(const unsigned int *stage, unsigned int j) {
+  const u32x4 *src = reinterpret_cast<const u32x4 *>(stage) + 2u * j;      // every lane reads the same address: a broadcast
+  const u32x4 a = src[0], b = src[1];
+  WorkItem it;
+  it.r0 = (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)a.x) |
+          ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)a.y) << 32);
+  it.r1 = (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)a.z) |
+          ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)a.w) << 32);
+  it.f = (unsigned int)__builtin_amdgcn_readfirstlane((int)b.x);
+  it.pad[0] = it.pad[1] = it.pad[2] = 0u;
+  return it;
+}
+
 // item -> entry of the work list: bands and slices are never both > 1, and one slice per frame is the common case
 template <bool SPILL>
 __device__ __forceinline__ unsigned int item_entry(unsigned int item, int slices) {
   return (SPILL || slices == 1) ? item : item / (unsigned int)slices;
 }
 
-// Work item -> frame.  k.planned: an entry of the work list (one frame per workgroup: frames without side data have been
-// answered by the planning kernels and are not in the list).  Otherwise the WINDOW form — a workgroup owns k.group >= 2
-// consecutive frames of the batch and looks them up itself; it is without work only if ALL of them lack side data, so
-// no period of key frames leaves an XCD idle, and the launch needs no planning kernels (small frames: tens of
-// thousands of workgroups per launch, where planning and the surplus workgroups cost 1.7 %).  kNoFrame there means
-// "this frame has no side data" (:219-221), not "the list has ended".
-// (frame_off / has_sd are kernel parameters of their own, `const ... __restrict__`: inside a struct they would lose
-//  that, and the compiler would fetch them with per-lane vector loads ordered against the kernel's stores instead of
-//  scalar loads — measured: the window form 2 % slower than round 5's, 11 % with a key frame every 2 frames)
-template <bool SPILL>
-__device__ __forceinline__ WorkItem get_item(const ScanK &k, const WorkItem *__restrict__ work,
-                                             const unsigned long long *__restrict__ frame_off, const unsigned char *__restrict__ has_sd,
-                                             unsigned long long n_records, unsigned long long rebase, unsigned int item) {
-  if (k.planned) return load_item(work, item_entry<SPILL>(item, k.slices));
-  WorkItem it;
-  unsigned long long r0, r1;
-  const bool sd = plan_frame(frame_off, has_sd, n_records, item, r0, r1);
-  it.r0 = r0 > rebase ? r0 - rebase : 0ull;
-  it.r1 = r1 > rebase ? r1 - rebase : 0ull;
-  it.f = sd ? item : kNoFrame;
-  it.pad[0] = it.pad[1] = it.pad[2] = 0u;
-  return it;
-}
-
 // One work item (the list entry `me`, or a slice of it) by one workgroup.  `has_next`: the same workgroup scans
-// item + 1 (the list entry `nx`, asked for when this item began) right after this one.  Frames without side data (:219-221) never get here:
-// plan_scatter_kernel has answered them.
+// item + 1 (the list entry parked at `stage_next`: readable after this item's first barrier) right after this one.
+// Frames without side data (:219-221) never get here: plan_scatter_kernel has answered them.
 template <int BLOCK, int UNROLL, int FB, int MODE, int VAR, int REC, bool SPILL>
 __device__ __forceinline__ void scan_item(
-    const unsigned char *__restrict__ mv, const WorkItem me, const WorkItem nx,
+    const unsigned char *__restrict__ mv, const WorkItem me, const unsigned int *stage_next,
     const unsigned int item, const ScanK &k, unsigned char *__restrict__ flags,
     unsigned int *spill_q, unsigned int *slice_ws, unsigned int *tickets, unsigned int *lds,
     NextStep<UNROLL> &ns, const bool has_next) {
@@ -717,7 +724,8 @@ __device__ __forceinline__ void scan_item(
       }
       if constexpr (REC == 8 && !SPILL) {
         if (has_next && k.slices == 1 && k.vec_need != 0u && trows > 0) {   // exactly when the next frame's phase 1 runs
-          // next frame of the list (`nx`; the list always ends in a kNoFrame entry): same pair alignment as above
+          // next frame of the list (parked in LDS when the workgroup started): same pair alignment as above
+          const WorkItem nx = staged_item(stage_next, 0u);
           const unsigned long long a = nx.r0, b = nx.r1;
           const bool sdn = nx.f != kNoFrame;
           const unsigned char *nb = mv + a * 8ull;
@@ -938,8 +946,7 @@ __device__ __forceinline__ void scan_item(
 template <int BLOCK, int UNROLL, int FB, int MODE, int VAR, int REC, bool SPILL>
 __global__ __launch_bounds__(BLOCK) void scan_frames_kernel(
     const unsigned char *__restrict__ mv, const WorkItem *__restrict__ work,
-    const unsigned long long *__restrict__ frame_off, const unsigned char *__restrict__ has_sd, unsigned long long n_records,
-    unsigned long long rebase, unsigned int item0, unsigned int n_items, ScanK k, unsigned char *__restrict__ flags,
+    unsigned int item0, unsigned int n_items, ScanK k, unsigned char *__restrict__ flags,
     unsigned int *spill_q, unsigned int *slice_ws, unsigned int *tickets, unsigned int *next_ticket) {
   extern __shared__ __attribute__((aligned(16))) unsigned int lds[];
   NextStep<UNROLL> ns;
@@ -965,32 +972,26 @@ __global__ __launch_bounds__(BLOCK) void scan_frames_kernel(
         nextv = __hip_atomic_fetch_add(next_ticket, (unsigned int)k.group, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (first >= n_items) return;
-    // the first frame is asked for before anything else is set up: its latency overlaps the kernel's scalar prologue
-    WorkItem me = get_item<SPILL>(k, work, frame_off, has_sd, n_records, rebase, first);
-    bool ended = false;
+    // the first entry is asked for before anything else is set up: its latency overlaps the kernel's scalar prologue;
+    // a workgroup that owns several frames (then slices == 1: items are list entries) fetches the others now, too
+    WorkItem me = load_item(work, item_entry<SPILL>(first, k.slices));
+    unsigned int *stage = lds + k.stage_word;
+    if (k.group > 1) {
+      if (resident) __syncthreads();                          // (the previous ticket's last reads of the staged entries)
+      stage_items(work, first, n_items, k.group, stage);      // published by the first frame's first barrier
+    }
     for (int g = 0; g < k.group; ++g) {
       const unsigned int item = first + (unsigned int)g;
-      if (item >= n_items) break;
-      // the NEXT frame of this workgroup is asked for now (scalar loads: they complete while this frame is scanned),
-      // so that a workgroup that scans several small frames pays that latency once, not once per frame
+      if (item >= n_items || me.f == kNoFrame) return;       // kNoFrame: the list has ended, every later item is past its end too
       const bool more = (g + 1 < k.group) && (item + 1u < n_items);
-      WorkItem nx = me;
-      if (more) nx = get_item<SPILL>(k, work, frame_off, has_sd, n_records, rebase, item + 1u);
-      if (me.f != kNoFrame) {
-        // (no barrier between items: every LDS read of an item precedes its last barrier, and the
-        //  next item's writes start with its own zeroing)
-        scan_item<BLOCK, UNROLL, FB, MODE, VAR, REC, SPILL>(mv, me, nx, item, k, flags, spill_q, slice_ws, tickets, lds, ns,
-                                                             more && k.prefetch);
-      } else if (k.planned) {
-        ended = true;                            // the list has ended: every later item is past its end too
-        break;
-      } else {
-        if (threadIdx.x == 0) store_flag(flags, item, 0, k.sys_flags);          // :219-221 — no side data: false
-        ns.have = false;
-      }
-      me = nx;
+      // (no barrier between items: every LDS read of an item precedes its last barrier, and the
+      //  next item's writes start with its own zeroing)
+      scan_item<BLOCK, UNROLL, FB, MODE, VAR, REC, SPILL>(mv, me, stage + 8u * ((unsigned int)g + 1u), item, k, flags, spill_q,
+                                                           slice_ws, tickets, lds, ns, more && k.prefetch);
+      if (!more) break;
+      me = staged_item(stage, (unsigned int)g + 1u);            // (parked before this workgroup's first barrier)
     }
-    if (!resident || ended) return;
+    if (!resident) return;
   }
 }
 
@@ -1158,14 +1159,13 @@ static hipError_t launch_one(const ScanLaunch &L) {
   }
   const unsigned long long items = (unsigned long long)L.n_frames * (unsigned long long)(SPILL ? 1 : L.k.slices);
   const unsigned long long group = (unsigned long long)(L.k.group > 0 ? L.k.group : 1);
-  WorkItem *work = static_cast<WorkItem *>(L.plan_ws);                         // nullptr in the window form (never read there)
-  unsigned int *next_ticket = work ? reinterpret_cast<unsigned int *>(work + (size_t)L.n_frames + 1u) + plan_blocks(L.n_frames) : nullptr;
+  WorkItem *work = static_cast<WorkItem *>(L.plan_ws);
+  unsigned int *next_ticket = reinterpret_cast<unsigned int *>(work + (size_t)L.n_frames + 1u) + plan_blocks(L.n_frames);
   if (kExperiments && L.k.resident > 0) {
     const unsigned long long want = (unsigned long long)(L.cu_count > 0 ? L.cu_count : 256) * (unsigned long long)L.k.resident;
     const unsigned long long wgs = (items + group - 1) / group;
     hipLaunchKernelGGL(kern, dim3((unsigned int)(wgs < want ? wgs : want)), dim3(BLOCK), L.lds_bytes + 16, L.stream, L.mv, work,
-                       L.frame_off, L.has_sd, L.n_records, L.rebase, 0u, (unsigned int)items, L.k, L.flags, L.spill_q, L.slice_ws,
-                       L.tickets, next_ticket);
+                       0u, (unsigned int)items, L.k, L.flags, L.spill_q, L.slice_ws, L.tickets, next_ticket);
     return hipGetLastError();
   }
   const unsigned long long chunk = L.item_chunk ? L.item_chunk : (1ull << 30);   // workgroups per launch: grid.x stays < 2^31
@@ -1173,8 +1173,8 @@ static hipError_t launch_one(const ScanLaunch &L) {
     const unsigned long long left = items - i0;
     const unsigned long long wgs = (left + group - 1) / group;
     const unsigned int n = (unsigned int)(wgs < chunk ? wgs : chunk);
-    hipLaunchKernelGGL(kern, dim3(n), dim3(BLOCK), L.lds_bytes, L.stream, L.mv, work, L.frame_off, L.has_sd, L.n_records,
-                       L.rebase, (unsigned int)i0, (unsigned int)items, L.k, L.flags, L.spill_q, L.slice_ws, L.tickets, next_ticket);
+    hipLaunchKernelGGL(kern, dim3(n), dim3(BLOCK), L.lds_bytes, L.stream, L.mv, work, (unsigned int)i0,
+                       (unsigned int)items, L.k, L.flags, L.spill_q, L.slice_ws, L.tickets, next_ticket);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
@@ -1250,17 +1250,14 @@ hipError_t launch_scan(const ScanLaunch &L) {
     e = hipMemsetAsync(L.tickets, 0, sizeof(unsigned int) * (size_t)L.n_frames, L.stream);
     if (e != hipSuccess) return e;
   }
-  const bool needs_plan = L.k.planned || (kExperiments && L.k.resident > 0);
-  if (!L.frame_off || L.rebase > L.n_records) return hipErrorInvalidValue;
-  if (needs_plan && (!L.plan_ws || ((uintptr_t)L.plan_ws & 31u) != 0u)) return hipErrorInvalidValue;
-  if (!L.k.planned && (L.k.group < 2 || L.k.slices != 1)) return hipErrorInvalidValue;     // window form: several whole frames per workgroup
-  if (needs_plan) {
+  if (!L.plan_ws || ((uintptr_t)L.plan_ws & 31u) != 0u || !L.frame_off || L.rebase > L.n_records) return hipErrorInvalidValue;
+  {
     WorkItem *work = static_cast<WorkItem *>(L.plan_ws);
     unsigned int *blk_cnt = reinterpret_cast<unsigned int *>(work + (size_t)L.n_frames + 1u);
     e = launch_plan(L, work, blk_cnt, blk_cnt + plan_blocks(L.n_frames));
     if (e != hipSuccess) return e;
   }
-  // (profiling: the event between planning and scan — also in the window form, where nothing was planned)
+  // (profiling: the event between planning and scan)
   if (L.ev_planned && (e = hipEventRecord(L.ev_planned, L.stream)) != hipSuccess) return e;
   switch (L.block) {
 #ifdef MTGPU_EXPERIMENTS

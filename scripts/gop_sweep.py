@@ -38,7 +38,10 @@ params = m.ScanParams.from_config(W, H, **kw)
 reps = (M + distinct - 1) // distinct
 counts = np.tile(np.diff(off.astype(np.int64)), reps)[:M]
 n_records = int(counts.sum())
-d_mv = torch.from_numpy(mv.view(np.uint8).copy()).to(dev).repeat(reps)[: n_records * 40].contiguous()
+compact = os.environ.get("GOP_COMPACT", "0") == "1"        # the 8-byte compact records of the host dispatcher instead
+REC = 8 if compact else 40
+tile = m.pack_records(mv).view(np.uint8).reshape(-1) if compact else mv.view(np.uint8)
+d_mv = torch.from_numpy(tile.copy()).to(dev).repeat(reps)[: n_records * REC].contiguous()
 
 
 def other_library(path, env=None):
@@ -60,6 +63,11 @@ def other_library(path, env=None):
 
 
 builds = [("new", m.MotionScanner(params, 0))]
+for spec_ in [x for x in os.environ.get("GOP_GROUPS", "").split(",") if x]:       # e.g. "1,2,2p,8p": MTGPU_GROUP [+ the work list]
+    os.environ["MTGPU_GROUP"] = spec_.rstrip("p")
+    builds.append((f"g{spec_}", m.MotionScanner(params, 0)))
+    os.environ.pop("MTGPU_GROUP")
+    pass
 prev = os.environ.get("GOP_PREV_LIB") or os.path.join(ROOT, "scripts", "libmtgpu_prev.so")
 if os.path.exists(prev) and os.environ.get("GOP_PREV", "1") != "0":
     builds.append(("prev", other_library(prev)))
@@ -97,14 +105,14 @@ for period in periods:
     off_big = np.concatenate([[0], np.cumsum(c)]).astype(np.int64)
     nrec = int(off_big[-1])
     d_off = torch.from_numpy(off_big).to(dev)
-    alg = 40 * nrec + 9 * F
+    alg = REC * nrec + 9 * F
     times = {name: [] for name, _ in builds}
     flags = {name: torch.empty(F, dtype=torch.uint8, device=dev) for name, _ in builds}
     for r in range(rounds + 2):
         for name, s in builds:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            s.check_frames_device(d_mv[: nrec * 40], d_off, None, flags[name])
+            (s.check_frames_device_compact if compact else s.check_frames_device)(d_mv[: nrec * REC], d_off, None, flags[name])
             e1.record()
             torch.cuda.synchronize()
             if r >= 2:
