@@ -432,9 +432,9 @@ def test_scan_batch_properties_full_size(gpu_scanner_factory, grid, cfg):
 def test_work_list_every_plan_size(gpu_scanner_factory, monkeypatch, n_frames, group):
     """The planning kernels at every size class: one block (<= 1024 frames), the fused form (<= 32 blocks: every block
     counts the frames before it again), the two-kernel form beyond, and more than 1024 x 1024 frames (every planning
-    block then walks several times 1024 frames) — with MTGPU_GROUP=1 (one frame per workgroup: the work list at every
-    size) and with the automatic grouping (from 4096 frames on, these tiny frames go two to eight to a workgroup: the
-    WINDOW form, no planning kernels, the workgroup answers its own frames without side data).  Tiny frames (0..3
+    block then walks several times 1024 frames) — with MTGPU_GROUP=1 (one list entry per workgroup) and with the
+    automatic grouping (from 4096 frames on, these tiny frames go two to eight consecutive ENTRIES to a workgroup,
+    which parks the entries of its later frames in LDS when it starts).  Tiny frames (0..3
     records, a third of them without side data, some with EMPTY side data), so that the oracle checks every flag.  VECTORS_NEEDED 0
     makes the three kinds of frames differ: no side data -> false, empty side data -> true (every cell is active),
     records -> true."""
