@@ -353,6 +353,8 @@ typedef struct mtgpu_pipe_stats {
                             * when mtgpu_pipe_acquire first hands them out)                         */
   uint32_t hip_streams;    /* HIP streams OWNED by the pipe: 0 — batches run on the context's pool of 8 streams      *
                             * (creating a stream costs ~3.5 ms, serialised by the runtime)                    */
+  uint64_t list_bytes;     /* device memory for the batches' work lists (32 bytes per frame a batch can hold): each *
+                            * pinned batch owns one, so that its scans allocate nothing                       */
 } mtgpu_pipe_stats;
 int mtgpu_pipe_get_stats(mtgpu_pipe *pipe, mtgpu_pipe_stats *out);
 

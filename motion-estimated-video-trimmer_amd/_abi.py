@@ -70,7 +70,7 @@ class CtxStatsC(C.Structure):
 class PipeStatsC(C.Structure):
     _fields_ = [("pinned_bytes", C.c_uint64), ("device_bytes", C.c_uint64), ("submits", C.c_uint64),
                 ("n_buffers", C.c_uint32), ("layout", C.c_int32), ("pin_us", C.c_uint64),
-                ("pinned_batches", C.c_uint32), ("hip_streams", C.c_uint32)]
+                ("pinned_batches", C.c_uint32), ("hip_streams", C.c_uint32), ("list_bytes", C.c_uint64)]
 
 
 assert C.sizeof(ScanParamsC) == 32 and C.sizeof(MergeResultC) == 40

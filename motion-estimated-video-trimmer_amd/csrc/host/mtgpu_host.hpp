@@ -599,7 +599,7 @@ class GpuBackend {
     mtgpu_pipe_stats ps;
     if (pipe_ && mtgpu_pipe_get_stats(pipe_, &ps) == MT_OK) {
       r.pipes = 1; r.hip_streams += ps.hip_streams; r.hip_events += ps.n_buffers;
-      r.pinned_bytes += ps.pinned_bytes; r.device_bytes += ps.device_bytes; r.submits = ps.submits;
+      r.pinned_bytes += ps.pinned_bytes; r.device_bytes += ps.device_bytes + ps.list_bytes; r.submits = ps.submits;
       r.pin_us = ps.pin_us; r.pinned_batches = ps.pinned_batches;
     }
     return r;

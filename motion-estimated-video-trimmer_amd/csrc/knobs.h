@@ -11,8 +11,7 @@
 // mtgpu_version() ends in "+experiments"):
 //    experiments   MTGPU_VARIANT (load variants of the 32-bit kernel), MTGPU_ALIGN=0 (streams start wherever the frame
 //                  starts), MTGPU_PREFETCH=0 (no next-frame prefetch), MTGPU_RESIDENT=K (K ticketed resident workgroups
-//                  per CU instead of one workgroup per work item), MTGPU_PLAN_CACHE=1 (one never-freed scratch block: what the
-//                  stream-ordered alloc / free pair of a call costs), MTGPU_DEFAULT_POOL, MTGPU_PIPE_STREAMS,
+//                  per CU instead of one workgroup per work item), MTGPU_PIPE_STREAMS,
 //                  MTGPU_PIPE_EAGER, MTGPU_EVENT_BLOCKING, MTGPU_MAX_TILE_KB, MTGPU_BAND_LDS_KB, MTGPU_MIN_LDS_KB,
 //                  MTGPU_FORCE_CHUNK, MTGPU_PACK_NT, MTGPU_PACK_PREFETCH, MTGPU_FORCE_BLOCK=256
 #pragma once

@@ -6,6 +6,7 @@
 
 #include <atomic>
 #include <cctype>
+#include <condition_variable>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -87,7 +88,29 @@ struct mtgpu_ctx {
   int group_request = 0; // MTGPU_GROUP: frames per workgroup, 0 = automatic
   int check_offsets = 0; // MTGPU_CHECK_OFFSETS=1: the device entry points verify "frame_off non-decreasing" first (one sync per call)
   int min_lds_kb = 0;    // MTGPU_MIN_LDS_KB: launch with at least this much LDS (caps workgroups per CU), 0 = automatic
-  hipMemPool_t pool = nullptr;   // private stream-ordered pool for launch scratch (freed blocks stay cached)
+  // Launch scratch (work lists of the device entry points, spill queues, slice tiles, merge workspaces): a ring of
+  // device blocks, each with the event of its last user.  Whoever takes a block makes ITS stream wait for that event,
+  // so a block never has two users at once, whatever streams and threads the launches come from.  (Through round 5
+  // this was a hipMemPool with hipMallocFromPoolAsync / hipFreeAsync.  Round 6 made every launch use scratch, and 16
+  // host threads on their own streams then saw launches trample each other's work lists — one wrong flag in a few
+  // hundred launches, also with a mutex around the pool calls, also with one stream per batch; with memory that a
+  // launch demonstrably owns, none: profiles/r06_host_stress_*.log.  The library no longer relies on cross-stream
+  // reuse inside the runtime's stream-ordered allocator.)
+  struct Scratch {
+    static constexpr int kSlots = 16;
+    static constexpr size_t kBig = 64u << 20;   // requests from here on wait for a block that is large enough rather than grow another
+    struct Slot {
+      void *p = nullptr; size_t cap = 0;
+      hipEvent_t ev = nullptr;          // recorded behind the last launch that used the block
+      hipStream_t last = nullptr;       // ... and the stream it ran on (a preference only: the event is waited for regardless)
+      bool recorded = false;
+      bool busy = false;                // a host thread is queueing work that uses the block (guarded by mu; the other
+    };                                  // fields of a busy slot belong to that thread)
+    std::mutex mu;
+    std::condition_variable cv;
+    Slot slot[kSlots];
+    uint64_t reserved = 0, reserved_high = 0;
+  } scratch;
   uint64_t merge_large_min = 4096;   // timestamp lists at least this long take the multi-workgroup merge (MTGPU_MERGE_LARGE_MIN)
   // Streams of the pipes (host dispatcher): ONE small pool per context, handed to staging batches round-robin,
   // instead of a stream per batch.  Creating a HIP stream costs ~3.5 ms and the runtime serialises it: 64 workers
@@ -370,13 +393,89 @@ int choose_group(const mtgpu_ctx *c, uint64_t n_records, uint32_t n_frames, int 
   return g < 1 ? 1 : g;
 }
 
-// Stream-ordered scratch from the context's own pool.  The device's default pool hands freed
-// blocks back to the OS at the next synchronisation (release threshold 0), so the per-launch
-// scratch of banded plans (4 bytes per record: gigabytes for a 20 GB batch) would be re-mapped
-// after every host sync; the private pool keeps its blocks (release threshold = max).
-hipError_t scratch_alloc(mtgpu_ctx *c, void **p, size_t bytes, hipStream_t st) {
-  if (c->pool) return hipMallocFromPoolAsync(p, bytes, c->pool, st);
-  return hipMallocAsync(p, bytes, st);
+// A scratch block of at least `bytes` for work queued on `st` (see mtgpu_ctx::Scratch).  The block is the caller's
+// until scratch_release, which must follow the LAST launch that uses it.  Preference: a block that is large enough and
+// whose last user has finished; an unused or small block to grow (small requests only); a block that is large enough
+// but still in use (the stream then waits for it).  Growing synchronises with the block's last user and calls
+// hipFree / hipMalloc: it happens while a context warms up, not in steady state.
+int scratch_acquire(mtgpu_ctx *c, size_t bytes, hipStream_t st, int *slot_out, void **p_out) {
+  using Scratch = mtgpu_ctx::Scratch;
+  Scratch &sc = c->scratch;
+  int pick = -1;
+  {
+    std::unique_lock<std::mutex> lock(sc.mu);
+    for (;;) {
+      // 1. a block this stream used last: stream order alone makes it safe, nothing to ask the runtime
+      for (int i = 0; i < Scratch::kSlots && pick < 0; ++i) {
+        const Scratch::Slot &s = sc.slot[i];
+        if (!s.busy && s.cap >= bytes && s.recorded && s.last == st) pick = i;
+      }
+      // 2. a block that is large enough and whose last user has finished
+      int fit_busy = -1, small_done = -1, small_busy = -1, unused = -1;
+      for (int i = 0; i < Scratch::kSlots && pick < 0; ++i) {
+        const Scratch::Slot &s = sc.slot[i];
+        if (s.busy) continue;
+        if (!s.recorded && s.cap >= bytes) { pick = i; break; }
+        if (!s.recorded) { if (unused < 0 || s.cap > sc.slot[unused].cap) unused = i; continue; }
+        const bool done = hipEventQuery(s.ev) == hipSuccess;
+        if (s.cap >= bytes) { if (done) pick = i; else if (fit_busy < 0) fit_busy = i; }
+        else if (done) { if (small_done < 0 || s.cap < sc.slot[small_done].cap) small_done = i; }
+        else if (small_busy < 0) small_busy = i;
+      }
+      (void)hipGetLastError();                                  // (hipEventQuery's "not ready" is not an error of ours)
+      // 3. small requests grow an idle block rather than wait; large ones (spill queues: gigabytes) wait for one that fits
+      if (pick < 0 && bytes < Scratch::kBig) pick = unused >= 0 ? unused : small_done;
+      if (pick < 0) pick = fit_busy;
+      if (pick < 0) pick = unused >= 0 ? unused : (small_done >= 0 ? small_done : small_busy);
+      if (pick >= 0) break;
+      sc.cv.wait(lock);                                          // every block is in another thread's hands this microsecond
+    }
+    sc.slot[pick].busy = true;
+  }
+  mtgpu_ctx::Scratch::Slot &s = sc.slot[pick];
+  hipError_t e = hipSuccess;
+  if (!s.ev) e = hipEventCreateWithFlags(&s.ev, hipEventDisableTiming);
+  if (e == hipSuccess && s.cap < bytes) {
+    if (s.recorded) e = hipEventSynchronize(s.ev);
+    if (e == hipSuccess && s.p) { e = hipFree(s.p); s.p = nullptr; }
+    const size_t old = s.cap;
+    s.cap = 0;
+    s.recorded = false;
+    void *np = nullptr;
+    const size_t want = bytes + bytes / 4 + 256;
+    if (e == hipSuccess) e = hipMalloc(&np, want);
+    if (e == hipSuccess) { s.p = np; s.cap = want; }
+    std::lock_guard<std::mutex> lock(sc.mu);
+    sc.reserved += s.cap;
+    sc.reserved -= old;
+    if (sc.reserved > sc.reserved_high) sc.reserved_high = sc.reserved;
+  } else if (e == hipSuccess && s.recorded) {
+    e = hipStreamWaitEvent(st, s.ev, 0);                        // after the block's last user, on whatever stream that was
+  }
+  if (e != hipSuccess) {
+    { std::lock_guard<std::mutex> lock(sc.mu); s.busy = false; }
+    sc.cv.notify_one();
+    return hip_fail(e, "launch scratch");
+  }
+  *slot_out = pick;
+  *p_out = s.p;
+  return MT_OK;
+}
+
+// The caller has queued its last use of the block on `st`.
+void scratch_release(mtgpu_ctx *c, int slot, hipStream_t st) {
+  mtgpu_ctx::Scratch &sc = c->scratch;
+  mtgpu_ctx::Scratch::Slot &s = sc.slot[slot];
+  if (hipEventRecord(s.ev, st) == hipSuccess) {
+    s.recorded = true;
+    s.last = st;
+  } else {                                                      // cannot tell when the work ends: wait for it here
+    (void)hipGetLastError();
+    (void)hipStreamSynchronize(st);
+    s.recorded = false;
+  }
+  { std::lock_guard<std::mutex> lock(sc.mu); s.busy = false; }
+  sc.cv.notify_one();
 }
 
 // Launches the scan on `st`; scratch (band centre counts, slice tiles + tickets) is allocated
@@ -384,7 +483,7 @@ hipError_t scratch_alloc(mtgpu_ctx *c, void **p, size_t bytes, hipStream_t st) {
 // flags_sys: 1 = d_flags is not device memory (system-scope result stores), 0 = device memory, -1 = ask the runtime
 int launch_scan_on(mtgpu_ctx *c, const void *d_mv, uint64_t n_records, const uint64_t *d_off,
                    const uint8_t *d_sd, uint32_t n_frames, uint8_t *d_flags, hipStream_t st, int rec_bytes = MT_MV_BYTES,
-                   int flags_sys = 0, uint64_t rebase = 0) {
+                   int flags_sys = 0, uint64_t rebase = 0, void *own_plan_ws = nullptr, size_t own_plan_ws_bytes = 0) {
   if (flags_sys < 0) {
     // a caller's pointer (the *_device entry points): device memory takes plain stores; anything else the runtime
     // knows of, or does not know at all, takes the system-scope ones
@@ -440,24 +539,22 @@ int launch_scan_on(mtgpu_ctx *c, const void *d_mv, uint64_t n_records, const uin
   if (c->min_lds_kb > 0) L.lds_bytes = std::max(L.lds_bytes, std::min(c->min_lds_kb * 1024, c->lds_max));
   L.stream = st;
   // launch scratch, one stream-ordered block: [work list + planning counts | spill queue or slice tiles + tickets]
-  const size_t plan_bytes = (mtgpu::plan_scratch_bytes(n_frames) + 255u) & ~(size_t)255u;
+  // the caller's own block for the work list (a pipe's batch), if it is large enough: the pool then serves only
+  // the spill queue / the slice tiles, i.e. nothing at all for single-tile plans
+  const bool own_plan = own_plan_ws && ((uintptr_t)own_plan_ws & 255u) == 0u && own_plan_ws_bytes >= mtgpu::plan_scratch_bytes(n_frames);
+  const size_t plan_bytes = own_plan ? 0u : ((mtgpu::plan_scratch_bytes(n_frames) + 255u) & ~(size_t)255u);
   size_t bytes = plan_bytes;
   if (L.k.bands > 1) bytes += sizeof(unsigned int) * ((size_t)(n_records - rebase) + 4);   // spill queue: a slot per record
   if (L.k.slices > 1)
     bytes += sizeof(unsigned int) * ((size_t)n_frames * (size_t)L.k.slices * (size_t)L.k.cnt_words + (size_t)n_frames + 4);
   void *scratch = nullptr;
+  int slot = -1;
   hipError_t e = hipSuccess;
-  static void *exp_cached = nullptr;                  // experiments build, MTGPU_PLAN_CACHE=1: ONE process-wide scratch block,
-  static size_t exp_cached_bytes = 0;                 // never freed — measures what the stream-ordered alloc/free pair costs
-  const bool exp_cache = mtgpu::kExperiments && exp_int("MTGPU_PLAN_CACHE", 0) != 0;
-  if (exp_cache) {
-    if (exp_cached_bytes < bytes) { (void)hipMalloc(&exp_cached, bytes * 2); exp_cached_bytes = bytes * 2; }
-    scratch = exp_cached;
-  } else {
-    e = scratch_alloc(c, &scratch, bytes, st);
+  if (bytes) {
+    const int rc0 = scratch_acquire(c, bytes, st, &slot, &scratch);
+    if (rc0 != MT_OK) return rc0;
   }
-  if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(scan scratch)");
-  L.plan_ws = scratch;
+  L.plan_ws = own_plan ? own_plan_ws : scratch;
   unsigned int *rest = reinterpret_cast<unsigned int *>(static_cast<unsigned char *>(scratch) + plan_bytes);
   if (L.k.bands > 1) L.spill_q = rest;
   if (L.k.slices > 1) {
@@ -484,9 +581,7 @@ int launch_scan_on(mtgpu_ctx *c, const void *d_mv, uint64_t n_records, const uin
     e = mtgpu::launch_scan(L);
   }
   if (e != hipSuccess) rc = hip_fail(e, "scan launch");
-  if (exp_cache) return rc;
-  hipError_t e2 = hipFreeAsync(scratch, st);
-  if (rc == MT_OK && e2 != hipSuccess) rc = hip_fail(e2, "hipFreeAsync");
+  if (slot >= 0) scratch_release(c, slot, st);
   return rc;
 }
 
@@ -526,9 +621,12 @@ int physical_device(int logical) {
   return logical >= 0 ? logical % n : logical;
 }
 int ctx_launch_scan(mtgpu_ctx *c, const void *d_mv, uint64_t n_records, const uint64_t *d_off,
-                    const uint8_t *d_sd, uint32_t n_frames, uint8_t *d_flags, hipStream_t st, int rec_bytes, int flags_in_host_memory) {
-  return launch_scan_on(c, d_mv, n_records, d_off, d_sd, n_frames, d_flags, st, rec_bytes, flags_in_host_memory ? 1 : 0);
+                    const uint8_t *d_sd, uint32_t n_frames, uint8_t *d_flags, hipStream_t st, int rec_bytes, int flags_in_host_memory,
+                    void *plan_ws, size_t plan_ws_bytes) {
+  return launch_scan_on(c, d_mv, n_records, d_off, d_sd, n_frames, d_flags, st, rec_bytes, flags_in_host_memory ? 1 : 0, 0,
+                        plan_ws, plan_ws_bytes);
 }
+size_t ctx_plan_ws_bytes(uint32_t n_frames) { return (plan_scratch_bytes(n_frames) + 255u) & ~(size_t)255u; }
 }  // namespace mtgpu
 
 #ifdef MTGPU_PHASE_TIMES
@@ -620,21 +718,6 @@ int mtgpu_create(const mt_scan_params *params, int device, mtgpu_ctx **out) {
   if (rc != MT_OK) { delete c; return rc; }
   e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete c; return hip_fail(e, "hipStreamCreate"); }
-  if (exp_int("MTGPU_DEFAULT_POOL", 0) == 0) {
-    hipMemPoolProps props;
-    std::memset(&props, 0, sizeof props);
-    props.allocType = hipMemAllocationTypePinned;
-    props.handleTypes = hipMemHandleTypeNone;
-    props.location.type = hipMemLocationTypeDevice;
-    props.location.id = device;
-    if (hipMemPoolCreate(&c->pool, &props) == hipSuccess) {
-      uint64_t keep = ~0ull;
-      (void)hipMemPoolSetAttribute(c->pool, hipMemPoolAttrReleaseThreshold, &keep);
-    } else {
-      c->pool = nullptr;                 // fall back to the device's default pool
-      (void)hipGetLastError();
-    }
-  }
   *out = c;
   return MT_OK;
 }
@@ -648,7 +731,10 @@ void mtgpu_destroy(mtgpu_ctx *c) {
   for (auto &t : c->prof.ev)
     for (hipEvent_t &e : t)
       if (e) { (void)hipEventDestroy(e); e = nullptr; }
-  if (c->pool) { (void)hipDeviceSynchronize(); (void)hipMemPoolDestroy(c->pool); }
+  for (auto &sl : c->scratch.slot) {
+    if (sl.ev) { if (sl.recorded) (void)hipEventSynchronize(sl.ev); (void)hipEventDestroy(sl.ev); sl.ev = nullptr; }
+    if (sl.p) { (void)hipFree(sl.p); sl.p = nullptr; }
+  }
   c->d_mv.release(); c->d_off.release(); c->d_sd.release(); c->d_flags.release(); c->d_misc.release();
   delete c;
 }
@@ -663,13 +749,11 @@ int mtgpu_get_stats(mtgpu_ctx *c, mtgpu_ctx_stats *out) {
     std::lock_guard<std::mutex> pl(c->pipe_mu);
     for (hipStream_t ps : c->pipe_streams) out->hip_streams += ps ? 1u : 0u;
   }
-  out->private_pool = c->pool ? 1u : 0u;
-  if (c->pool) {
-    uint64_t cur = 0, high = 0;
-    HIP_TRY(hipMemPoolGetAttribute(c->pool, hipMemPoolAttrReservedMemCurrent, &cur));
-    HIP_TRY(hipMemPoolGetAttribute(c->pool, hipMemPoolAttrReservedMemHigh, &high));
-    out->pool_reserved_bytes = cur;
-    out->pool_reserved_high = high;
+  out->private_pool = 1u;
+  {
+    std::lock_guard<std::mutex> sl(c->scratch.mu);
+    out->pool_reserved_bytes = c->scratch.reserved;
+    out->pool_reserved_high = c->scratch.reserved_high;
   }
   return MT_OK;
 }
@@ -677,7 +761,25 @@ int mtgpu_get_stats(mtgpu_ctx *c, mtgpu_ctx_stats *out) {
 int mtgpu_trim(mtgpu_ctx *c) {
   if (!c) return fail(MT_ERR_INVALID, "ctx is NULL");
   HIP_TRY(hipSetDevice(c->device));
-  if (c->pool) HIP_TRY(hipMemPoolTrimTo(c->pool, 0));
+  // blocks nobody holds and whose last user has finished go back to the device; the others stay
+  mtgpu_ctx::Scratch &sc = c->scratch;
+  for (int i = 0; i < mtgpu_ctx::Scratch::kSlots; ++i) {
+    mtgpu_ctx::Scratch::Slot &s = sc.slot[i];
+    {
+      std::lock_guard<std::mutex> lock(sc.mu);
+      if (s.busy || !s.p) continue;
+      if (s.recorded && hipEventQuery(s.ev) != hipSuccess) { (void)hipGetLastError(); continue; }
+      s.busy = true;                                            // ours while it is being freed
+    }
+    const hipError_t e = hipFree(s.p);
+    {
+      std::lock_guard<std::mutex> lock(sc.mu);
+      if (e == hipSuccess) { sc.reserved -= s.cap; s.p = nullptr; s.cap = 0; s.recorded = false; }
+      s.busy = false;
+    }
+    sc.cv.notify_one();
+    if (e != hipSuccess) return hip_fail(e, "hipFree(scratch)");
+  }
   return MT_OK;
 }
 
@@ -716,16 +818,17 @@ namespace {
 // queued — costs one small kernel and one stream synchronisation per call, which is why it is opt-in.
 int check_offsets_on(mtgpu_ctx *c, const uint64_t *d_off, uint32_t n_frames, hipStream_t st) {
   void *d_bad = nullptr;
-  hipError_t e = scratch_alloc(c, &d_bad, sizeof(unsigned int), st);
-  if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(offset check)");
+  int slot = -1;
+  const int rc0 = scratch_acquire(c, sizeof(unsigned int), st, &slot, &d_bad);
+  if (rc0 != MT_OK) return rc0;
   unsigned int first_bad = 0xffffffffu;
-  e = hipMemsetAsync(d_bad, 0xff, sizeof(unsigned int), st);
+  hipError_t e = hipMemsetAsync(d_bad, 0xff, sizeof(unsigned int), st);
   if (e == hipSuccess)
     e = mtgpu::launch_check_offsets(reinterpret_cast<const unsigned long long *>(d_off), n_frames,
                                     static_cast<unsigned int *>(d_bad), st);
   if (e == hipSuccess) e = hipMemcpyAsync(&first_bad, d_bad, sizeof first_bad, hipMemcpyDeviceToHost, st);
   const hipError_t e2 = hipStreamSynchronize(st);
-  (void)hipFreeAsync(d_bad, st);
+  scratch_release(c, slot, st);
   if (e != hipSuccess) return hip_fail(e, "frame_off check");
   if (e2 != hipSuccess) return hip_fail(e2, "hipStreamSynchronize(frame_off check)");
   if (first_bad != 0xffffffffu)
@@ -946,7 +1049,11 @@ int mtgpu_merge_timestamps_device(mtgpu_ctx *c, const double *d_ts, uint64_t n, 
   hipStream_t st = static_cast<hipStream_t>(stream);
   const size_t wsb = merge_ts_ws_bytes(c, n) + 64;               // + the parameter block
   void *scratch = nullptr;
-  HIP_TRY(scratch_alloc(c, &scratch, wsb, st));
+  int slot = -1;
+  {
+    const int rc0 = scratch_acquire(c, wsb, st, &slot, &scratch);
+    if (rc0 != MT_OK) return rc0;
+  }
   unsigned char *w = static_cast<unsigned char *>(scratch);
   int rc = MT_OK;
   hipError_t e = mtgpu::launch_store_params(*mp, reinterpret_cast<mt_merge_params *>(w), st);   // by value: captured now
@@ -954,8 +1061,7 @@ int mtgpu_merge_timestamps_device(mtgpu_ctx *c, const double *d_ts, uint64_t n, 
   if (rc == MT_OK)
     rc = merge_ts_on(c, d_ts, n, reinterpret_cast<const mt_merge_params *>(w), job_semantics, w + 64, d_seg, seg_cap,
                      d_res, st);
-  hipError_t e2 = hipFreeAsync(scratch, st);
-  if (rc == MT_OK && e2 != hipSuccess) rc = hip_fail(e2, "hipFreeAsync");
+  scratch_release(c, slot, st);
   return rc;
 }
 

@@ -61,6 +61,8 @@ struct mtgpu_batch {
   uint8_t *h_flags = nullptr;
   // what the kernel dereferences: the device view of the pinned block (zero-copy) or a device mirror
   unsigned char *d_stage = nullptr;  // the mirror to free later (nullptr with zero-copy)
+  void *d_plan = nullptr;            // device memory for this batch's work list (ctx_plan_ws_bytes(cap_frames)): its scans
+  size_t plan_bytes = 0;             // allocate nothing — a batch has at most one launch in flight
   unsigned char *d_mv = nullptr;
   uint64_t *d_off = nullptr;
   uint8_t *d_sd = nullptr;
@@ -110,6 +112,7 @@ void free_batch(mtgpu_batch *b) {
   if (b->stream) (void)hipStreamSynchronize(b->stream);
   if (b->h_stage) (void)hipHostFree(b->h_stage);
   if (b->d_stage) (void)hipFree(b->d_stage);
+  if (b->d_plan) (void)hipFree(b->d_plan);
   if (b->done) (void)hipEventDestroy(b->done);
   if (b->stream && b->own_stream) (void)hipStreamDestroy(b->stream);
   delete b;
@@ -142,6 +145,7 @@ size_t aux_bytes_for(uint32_t cap_frames, size_t *flags_off = nullptr) {
 int pin_block(mtgpu_batch *b, uint64_t records, bool inject_failure = false) {
   int rc = MT_OK;
   unsigned char *h_new = nullptr, *d_new = nullptr, *dev_view = nullptr;
+  void *plan_new = nullptr;
   size_t hdr = 0;
   const size_t sbytes = stage_bytes_for(b->cap_frames, records, b->rec_bytes, &hdr);
   size_t flags_off = 0;
@@ -159,6 +163,12 @@ int pin_block(mtgpu_batch *b, uint64_t records, bool inject_failure = false) {
   } else {
     PIPE_TRY(hipMalloc(reinterpret_cast<void **>(&d_new), bytes));
     dev_view = d_new;
+  }
+  if (!b->d_plan) {                                  // (frames per batch never grow: allocated once)
+    PIPE_TRY(hipMalloc(&plan_new, mtgpu::ctx_plan_ws_bytes(b->cap_frames)));
+    b->d_plan = plan_new;
+    b->plan_bytes = mtgpu::ctx_plan_ws_bytes(b->cap_frames);
+    plan_new = nullptr;
   }
   if (b->h_stage) (void)hipHostFree(b->h_stage);
   if (b->d_stage) (void)hipFree(b->d_stage);
@@ -367,7 +377,7 @@ int mtgpu_pipe_submit(mtgpu_pipe *p, mtgpu_batch *b) {
       goto bad;
     }
     rc = mtgpu::ctx_launch_scan(p->ctx, b->d_mv, b->n_records, b->d_off, b->d_sd, b->n_frames, b->d_flags, st,
-                                b->rec_bytes, b->zero_copy ? 1 : 0);
+                                b->rec_bytes, b->zero_copy ? 1 : 0, b->d_plan, b->plan_bytes);
     if (rc != MT_OK) goto bad;
     if (!b->zero_copy)
       PIPE_TRY(hipMemcpyAsync(b->h_flags, b->d_flags, b->n_frames, hipMemcpyDeviceToHost, st));
@@ -438,6 +448,7 @@ int mtgpu_pipe_get_stats(mtgpu_pipe *p, mtgpu_pipe_stats *out) {
     if (b->h_stage) {                                  // pinned so far (the others pin on first use)
       out->pinned_bytes += b->block_bytes;
       if (!b->zero_copy) out->device_bytes += b->block_bytes;
+      out->list_bytes += b->plan_bytes;
       out->pinned_batches += 1;
     }
   out->pin_us = p->pin_us.load();

@@ -359,6 +359,34 @@ __device__ __forceinline__ void bump_cells(unsigned int *cnt, unsigned int c0, u
   }
 }
 
+// `r` votes for each of the cells [c0, c0 + n) of the tile (n <= 64, consecutive cells of one row), by a whole wave:
+// lane i takes the i-th counter word the cells touch — the word-at-once step of bump_cells, every word in parallel.
+template <int FB, int MODE>
+__device__ __forceinline__ void bump_cells_wave(unsigned int *cnt, unsigned int c0, unsigned int n, unsigned int r, unsigned int cap,
+                                                unsigned int lane) {
+  constexpr unsigned int CPW = 32u / FB, FM = (1u << FB) - 1u;
+  const unsigned int rr = r < cap ? r : cap;
+  constexpr unsigned int EVERY = 0xffffffffu / FM;                       // bit 0 of every field
+  const unsigned int low_rr = EVERY * ((1u << rr) - 1u), cap_ones = EVERY * ((1u << cap) - 1u);
+  const unsigned int end = c0 + n, first_w = c0 / CPW, last_w = (end - 1u) / CPW;
+  const unsigned int wi = first_w + lane;
+  if (wi > last_w) return;
+  const unsigned int lo = wi == first_w ? c0 - first_w * CPW : 0u, hi = wi == last_w ? end - last_w * CPW : CPW;
+  const unsigned int x = cnt[wi];
+  const unsigned int sel = (hi == CPW ? 0xffffffffu : (1u << (hi * FB)) - 1u) & ~((1u << (lo * FB)) - 1u);
+  const unsigned int m = (((x << rr) | low_rr) & cap_ones & sel) & ~x;   // (see bump_cells)
+  if (m != 0u) {
+    const unsigned int lost = m & atomicOr(&cnt[wi], m);                 // bits somebody else set between look and OR
+    if (lost != 0u) {
+#pragma unroll
+      for (unsigned int q = 0; q < CPW; ++q) {
+        const unsigned int l = (unsigned int)__popc((lost >> (q * FB)) & FM);
+        if (l != 0u) bump_n<FB, MODE>(cnt, wi * CPW + q, l, cap);
+      }
+    }
+  }
+}
+
 // Threshold + cell mapping + vote for one record (src/motion_scanner.cpp:246-267).
 // [t0,t1) = grid rows this tile tracks.
 template <int FB, int MODE, bool SPILL>
@@ -389,6 +417,37 @@ __device__ __forceinline__ void vote(const MvFields m, const ScanK &k, int t0, i
     if (any == 0ull) return;
     const int lane = (int)(threadIdx.x & 63u);
     const unsigned int key = in ? (((unsigned int)gy << 15) | (unsigned int)gx) : 0xffffffffu;   // gx, gy < 32768
+    if constexpr (MODE == MODE_UNARY && FB >= 2 && FB <= 8) {
+      // DENSE wave instruction — all 64 records vote and fall, in order, into consecutive cells of one grid row, R = 1, 2
+      // or 4 records per cell: what dense motion (a camera pan) looks like in raster-ordered records.  The general path
+      // below (runs, queue segments: a shuffle, eight ballots and 64-bit bit-scans per wave instruction) makes such input
+      // instruction-bound; here the wave's votes ARE one span: the counter words it touches are voted in parallel, one
+      // lane each, and ONE 8-byte span entry goes to the queue.  Same counter state and same replayed votes as the
+      // general path (saturating counts commute).  Needs the whole wave (the calls for head records and tails do not
+      // have it) and R <= 4 < ... the entry format's run field; vec_need > 4 cuts runs every 4 lanes anyway.
+      if (any == ~0ull && __ballot(true) == ~0ull) {
+        const unsigned int key0 = (unsigned int)__builtin_amdgcn_readfirstlane((int)key);
+        const unsigned int k1 = (unsigned int)__builtin_amdgcn_readlane((int)key, 1);
+        const unsigned int k2 = (unsigned int)__builtin_amdgcn_readlane((int)key, 2);
+        const unsigned int sh = k1 != key0 ? 0u : (k2 != key0 ? 1u : 2u);                 // log2 R
+        if (__ballot(key != key0 + ((unsigned int)lane >> sh)) == 0ull) {
+          const unsigned int n_cells = 64u >> sh, R = 1u << sh;
+          const int gy0 = (int)(key0 >> 15), gx0 = (int)(key0 & 0x7fffu);
+          if (!SPILL || (unsigned int)(gy0 - t0) < (unsigned int)(t1 - t0))
+            bump_cells_wave<FB, MODE>(cnt, (unsigned int)((gy0 - t0) * k.gw + gx0), n_cells, R, k.vec_need, (unsigned int)lane);
+          if constexpr (SPILL) {
+            if (gy0 >= sq.q_lo && lane == 0) {
+              if (n_cells >= 3u) {                // (always: 16, 32 or 64 cells)
+                const unsigned int at = atomicAdd(sq.tail + 1, 2u);
+                sq.q[at] = ((R - 1u) << 30) | key0;
+                sq.q[at + 1u] = n_cells;
+              }
+            }
+          }
+          return;
+        }
+      }
+    }
     const unsigned int prev = (unsigned int)__shfl_up((int)key, 1);
     // a queue entry carries a run of at most 4 (two spare bits): where a field can count beyond 4, runs are cut
     // every 4 lanes so that no vote is lost to the entry format

@@ -203,6 +203,22 @@ def test_multi_device_paths_of_the_host_layer_on_aliased_devices(streams64):
     assert sorted(json.dumps(j["segments"]) + j["input"] for j in jobs) == sorted(json.dumps(j["segments"]) + j["input"] for j in jobs1)
 
 
+def test_host_layer_repeated_runs_stay_bit_exact(streams64):
+    """The same 24 videos through process_batch again and again (MTGPU_STRESS_RUNS, default 6; a soak sets it higher):
+    16 workers on four aliased contexts, then 8 x 1 on one — tiny batches (10-20 frames per submit) from many threads on
+    the context's shared streams, each launch = planning kernel + scan kernel.  Round 6 saw ONE job of this shape with
+    one motion frame missing, once (gpurun_out/r06/dense_fast_path_1.log), while launches took their work-list memory from
+    the context's stream-ordered pool; a batch now owns that memory (mtgpu_pipe_stats.list_bytes).  Every job of every
+    run is compared with the oracle-driven answer."""
+    d, paths, cases = streams64
+    some = paths[:24]
+    for it in range(int(os.environ.get("MTGPU_STRESS_RUNS", "6"))):
+        for streams, threads, env in ((8, 2, {"MTGPU_ALIAS_DEVICES": "4"}), (8, 1, None)):
+            r, jobs, s = _run(some, streams, threads, d, env)
+            assert r.returncode == 0, (it, r.stderr[-2000:])
+            _check_all(jobs, cases, some)
+
+
 def test_batch_sized_from_budget_devices_and_videos_when_no_counts_are_given(streams64):
     """`mtgpu_scan_file --streams 0 --threads 0` sizes the batch with the host layer's own rule (default_batch_sizing:
     CPU budget, devices, videos — hand cases in tests/test_reference_host.py), honouring PARALLEL_STREAMS and

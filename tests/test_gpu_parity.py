@@ -1367,6 +1367,70 @@ def test_settings_change_while_other_threads_scan(gpu_scanner_factory):
     assert not errors, errors
 
 
+def test_many_threads_and_streams_never_share_launch_scratch(gpu_scanner_factory):
+    """Every launch of the device entry points takes a scratch block (its work list) from the context's ring; sixteen
+    threads, each on its own stream, launch small batches back to back through ONE context — three different batches per
+    thread in turn, so that a launch that read another launch's list would answer for the wrong frames.  (The
+    runtime's stream-ordered allocator, which served this scratch through round 5, did exactly that under this load:
+    profiles/r06_host_stress_*.log.)  2400 launches, every flag compared with the oracle."""
+    import threading
+    import torch
+    spec = synth.spec_1080p(seed=41, sub=1)
+    spec.events = synth.scripted_events(spec, 90)
+    p = ob.params_from_config(1920, 1080, vectors_needed=1)
+    s = gpu_scanner_factory(p)
+    errors, lock = [], threading.Lock()
+
+    def worker(w):
+        try:
+            rng = np.random.default_rng(500 + w)
+            st = torch.cuda.Stream()
+            batches = []
+            for _ in range(3):
+                frames = [synth.gen_frame(spec, int(i)) for i in rng.integers(0, 90, size=int(rng.integers(3, 17)))]
+                b = m.FrameBatch.from_frames(frames)
+                batches.append((torch.from_numpy(b.mv.view(np.uint8).reshape(-1).copy()).cuda(),
+                                torch.from_numpy(b.frame_off.astype(np.int64)).cuda(), torch.from_numpy(b.has_sd).cuda(),
+                                ob.scan_frames(p, b.mv, b.frame_off, b.has_sd),
+                                torch.empty(len(frames), dtype=torch.uint8, device="cuda")))
+            torch.cuda.synchronize()
+            for it in range(50):
+                for d_mv, d_off, d_sd, want, d_flags in batches:          # three launches in flight per stream
+                    s.check_frames_device(d_mv, d_off, d_sd, d_flags, stream=st.cuda_stream)
+                st.synchronize()
+                for d_mv, d_off, d_sd, want, d_flags in batches:
+                    assert np.array_equal(d_flags.cpu().numpy(), want), (w, it)
+        except BaseException as e:          # noqa: BLE001 - reported to the main thread
+            with lock:
+                errors.append((w, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(w,)) for w in range(16)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:3]
+    assert s.stats()["pool_reserved_bytes"] > 0
+
+
+def test_device_entry_points_under_real_thread_concurrency(tmp_path):
+    """tests/cpp/device_entry_stress.cpp: sixteen std::threads (no interpreter lock between them), each on its own HIP
+    stream, 150 x 3 launches of small batches through ONE context — the launches' work lists come from the context's
+    scratch ring.  Expected flags are known by construction; every launch is compared.  (This is the load under which
+    the runtime's stream-ordered allocator let launches share scratch: profiles/r06_host_stress_*.log.)"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.dirname(m.LIB_PATH)
+    exe = str(tmp_path / "device_entry_stress")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-D__HIP_PLATFORM_AMD__",
+                           "-I" + os.path.join(root, "include"), "-I/opt/rocm/include",
+                           os.path.join(root, "tests", "cpp", "device_entry_stress.cpp"), "-o", exe, "-L" + pkg, "-lmtgpu",
+                           "-L/opt/rocm/lib", "-lamdhip64", "-lpthread", "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe, "16", os.environ.get("MTGPU_STRESS_ITERS", "150")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.startswith("ok "), out.stdout + out.stderr[-2000:]
+
+
 def test_launch_timing_events(gpu_scanner_factory):
     """mtgpu_profile_enable / mtgpu_profile_read: one event triple per scan launch (planning | scan kernel), a ring of
     64 that a 65th launch drains by itself, totals reset by every read, nothing recorded while off."""
