@@ -104,22 +104,24 @@ int mtgpu_get_params(const mtgpu_ctx *ctx, mt_scan_params *out);
 /*
  * What a context holds on the device, and how to give it back.  No reference counterpart: the
  * reference's per-scanner memory is the grid_votes vector (src/motion_scanner.cpp:199), which lives
- * in LDS here.  Launch scratch (the spill queue of banded plans: 4 bytes per record of the largest
- * batch scanned so far; slice tiles; the merge workspace: 24 bytes per timestamp) comes from a
- * private stream-ordered pool that KEEPS freed blocks until mtgpu_trim or mtgpu_destroy, so that a
- * steady stream of batches never re-maps memory.  A host that scans one huge batch
- * and then idles should call mtgpu_trim; the C++ host layer does so between videos when a context has one user.
+ * in LDS here.  Launch scratch (the work list of a device-resident scan: 32 bytes per frame; the spill queue of
+ * banded plans: 4 bytes per record of the largest batch scanned so far; slice tiles; the merge workspace: 24 bytes
+ * per timestamp) comes from a ring of up to 16 device blocks owned by the context, each guarded by the event of its
+ * last user (a block never has two users, on whatever streams and threads the launches run), and KEPT until
+ * mtgpu_trim or mtgpu_destroy, so that a steady stream of batches never allocates.  A host that scans
+ * one huge batch and then idles should call mtgpu_trim; the C++ host layer does so between videos when a context has
+ * one user.
  */
 typedef struct mtgpu_ctx_stats {
   uint64_t staging_device_bytes;  /* grow-only device buffers of the HOST-pointer entry points   */
-  uint64_t pool_reserved_bytes;   /* device memory the scratch pool holds right now             */
+  uint64_t pool_reserved_bytes;   /* device memory the scratch ring holds right now             */
   uint64_t pool_reserved_high;    /* its high-water mark                                        */
   uint32_t hip_streams;           /* streams owned by the context: its own + the pipe-stream pool */
-  uint32_t private_pool;          /* 1: scratch from the private pool; 0: device default pool   */
+  uint32_t private_pool;          /* 1: scratch from the context's own ring of blocks (always, since round 6) */
 } mtgpu_ctx_stats;
 int mtgpu_get_stats(mtgpu_ctx *ctx, mtgpu_ctx_stats *out);
-/* Return the scratch pool's UNUSED blocks to the device (scratch of launches still in flight stays);
- * safe at any time, from any thread; scans that follow simply map scratch again. */
+/* Return the scratch blocks nobody uses to the device (blocks of launches still in flight stay);
+ * safe at any time, from any thread; scans that follow simply allocate again. */
 int mtgpu_trim(mtgpu_ctx *ctx);
 
 /* Launch timing — a profiling aid, off by default.  While on, every scan launched through the context records three
