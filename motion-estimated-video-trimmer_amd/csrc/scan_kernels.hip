@@ -421,30 +421,53 @@ __device__ __forceinline__ void vote(const MvFields m, const ScanK &k, int t0, i
       // DENSE wave instruction — all 64 records vote and fall, in order, into consecutive cells of one grid row, R = 1, 2
       // or 4 records per cell: what dense motion (a camera pan) looks like in raster-ordered records.  The general path
       // below (runs, queue segments: a shuffle, eight ballots and 64-bit bit-scans per wave instruction) makes such input
-      // instruction-bound; here the wave's votes ARE one span: the counter words it touches are voted in parallel, one
-      // lane each, and ONE 8-byte span entry goes to the queue.  Same counter state and same replayed votes as the
-      // general path (saturating counts commute).  Needs the whole wave (the calls for head records and tails do not
-      // have it) and R <= 4 < ... the entry format's run field; vec_need > 4 cuts runs every 4 lanes anyway.
+      // instruction-bound; here the pattern is read off a few lanes (first run: lanes 0..3, run length: the second
+      // cell's lanes), verified with ONE ballot, and the wave's votes are: the first cell (R - ph votes: the instruction
+      // may start inside a cell — where a frame's records start, and how many head records the line alignment peeled,
+      // is data), the cells in between (R each: their counter words voted in parallel, one lane per word), the last
+      // cell (the rest).  The queue gets ONE span for the cells in between and a single each for a cut first / last
+      // cell — what the general path would have written.  Same counter state and same replayed votes (saturating
+      // counts commute).  Needs the whole wave (the calls for head records and tails do not have it).
       if (any == ~0ull && __ballot(true) == ~0ull) {
         const unsigned int key0 = (unsigned int)__builtin_amdgcn_readfirstlane((int)key);
         const unsigned int k1 = (unsigned int)__builtin_amdgcn_readlane((int)key, 1);
         const unsigned int k2 = (unsigned int)__builtin_amdgcn_readlane((int)key, 2);
-        const unsigned int sh = k1 != key0 ? 0u : (k2 != key0 ? 1u : 2u);                 // log2 R
-        if (__ballot(key != key0 + ((unsigned int)lane >> sh)) == 0ull) {
-          const unsigned int n_cells = 64u >> sh, R = 1u << sh;
-          const int gy0 = (int)(key0 >> 15), gx0 = (int)(key0 & 0x7fffu);
-          if (!SPILL || (unsigned int)(gy0 - t0) < (unsigned int)(t1 - t0))
-            bump_cells_wave<FB, MODE>(cnt, (unsigned int)((gy0 - t0) * k.gw + gx0), n_cells, R, k.vec_need, (unsigned int)lane);
-          if constexpr (SPILL) {
-            if (gy0 >= sq.q_lo && lane == 0) {
-              if (n_cells >= 3u) {                // (always: 16, 32 or 64 cells)
-                const unsigned int at = atomicAdd(sq.tail + 1, 2u);
-                sq.q[at] = ((R - 1u) << 30) | key0;
-                sq.q[at + 1u] = n_cells;
+        const unsigned int k3 = (unsigned int)__builtin_amdgcn_readlane((int)key, 3);
+        const unsigned int L1 = k1 != key0 ? 1u : (k2 != key0 ? 2u : (k3 != key0 ? 3u : 4u));     // votes for the first cell
+        const unsigned int a1 = (unsigned int)__builtin_amdgcn_readlane((int)key, (int)L1 + 1);
+        const unsigned int a2 = (unsigned int)__builtin_amdgcn_readlane((int)key, (int)L1 + 2);
+        const unsigned int a3 = (unsigned int)__builtin_amdgcn_readlane((int)key, (int)L1 + 3);
+        const unsigned int R = a1 != key0 + 1u ? 1u : (a2 != key0 + 1u ? 2u : (a3 != key0 + 1u ? 3u : 4u));
+        if (R != 3u && L1 <= R) {
+          const unsigned int sh = R >> 1, ph = R - L1;                                              // log2 R; lanes of the first cell that belong to the instruction before
+          if (__ballot(key != key0 + (((unsigned int)lane + ph) >> sh)) == 0ull) {
+            const unsigned int n_cells = ((63u + ph) >> sh) + 1u, last = ((63u + ph) & (R - 1u)) + 1u;
+            const int gy0 = (int)(key0 >> 15), gx0 = (int)(key0 & 0x7fffu);
+            const bool cut = ph != 0u;                                                              // first and last cell hold fewer than R votes
+            if (!SPILL || (unsigned int)(gy0 - t0) < (unsigned int)(t1 - t0)) {
+              const unsigned int c0 = (unsigned int)((gy0 - t0) * k.gw + gx0);
+              if (!cut) {
+                bump_cells_wave<FB, MODE>(cnt, c0, n_cells, R, k.vec_need, (unsigned int)lane);
+              } else {
+                bump_cells_wave<FB, MODE>(cnt, c0 + 1u, n_cells - 2u, R, k.vec_need, (unsigned int)lane);
+                if (lane == 63) bump_n<FB, MODE>(cnt, c0, L1, k.vec_need);
+                if (lane == 62) bump_n<FB, MODE>(cnt, c0 + n_cells - 1u, last, k.vec_need);
               }
             }
+            if constexpr (SPILL) {
+              if (gy0 >= sq.q_lo && lane == 0) {
+                const unsigned int at = atomicAdd(sq.tail + 1, 2u);                                 // (n_cells - 2 >= 14: always a span)
+                sq.q[at] = ((R - 1u) << 30) | (cut ? key0 + 1u : key0);
+                sq.q[at + 1u] = cut ? n_cells - 2u : n_cells;
+                if (cut) {
+                  const unsigned int b1 = atomicAdd(sq.tail, 2u);
+                  sq.q[sq.n - 1u - b1] = ((L1 - 1u) << 30) | key0;
+                  sq.q[sq.n - 2u - b1] = ((last - 1u) << 30) | (key0 + n_cells - 1u);
+                }
+              }
+            }
+            return;
           }
-          return;
         }
       }
     }
