@@ -376,8 +376,8 @@ int choose_group(const mtgpu_ctx *c, uint64_t n_records, uint32_t n_frames, int 
       if ((uint64_t)n_frames >= cus * 4ull) g = 4;
       else if ((uint64_t)n_frames >= cus * 2ull) g = 2;
     }
-    // Round 6, with the window form (a workgroup that owns several frames needs no work list and issues the next
-    // frame's first loads before this frame's cluster test): profiles/r06_group_ab.log, wall clock per call —
+    // Round 6 (a workgroup that owns several list entries parks them in LDS when it starts and issues the next frame's
+    // first loads before this frame's cluster test): profiles/r06_group_ab.log, wall clock per call —
     //   compact records on tiles that share a CU (1080p: 261 KB frames, 37 us per workgroup, of which ~3 us are
     //   start-up): two frames per workgroup 635 -> 594 us at 16 384 frames, 174 -> 160 us at 4096 (four: 601 / 161);
     //   40-byte records on a one-workgroup-per-CU tile (4K: 5.2 MB frames): 2895 -> 2881 us with two on equal frames,

@@ -883,7 +883,7 @@ __device__ __forceinline__ void scan_item(
     //             shared by the CU's waves, the invalidate is not per wave) and waits for it
     //             (vmcnt(0)); the barrier keeps every other wave's loads behind that wait; then
     //             plain loads.  The workspace is ordinary coarse-grained device memory
-    //             (hipMallocAsync pool) that earlier launches may have cached on this CU: the
+    //             (the context's scratch ring) that earlier launches may have cached on this CU: the
     //             acquire is what makes those stale L1 lines unreachable.  A line of another
     //             workgroup's tile cannot sit stale in THIS XCD's L2 from inside the launch (no
     //             wave reads a tile before the ticket says it is complete), and lines cached by

@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """What a scan CALL costs beyond its scan kernel: N back-to-back calls on one stream, wall clock between two device
 synchronisations, for the library in the tree, scripts/libmtgpu_prev.so (the previous round: one workgroup per frame,
-no planning kernels, no scratch for single-tile plans) and the experiments build with and without MTGPU_PLAN_CACHE=1
-(no stream-ordered alloc / free per call).  Usage: call_cost.py [workload frames [compact]]"""
+no planning kernels, no scratch for single-tile plans) and, when it is built, the experiments build.
+Usage: call_cost.py [workload frames [compact]]
+(The `exp+cache` rows of profiles/r06_call_cost.txt came from MTGPU_PLAN_CACHE=1 of an earlier build of the round: one
+never-freed scratch block in place of the stream-ordered alloc / free pair — which the scratch ring replaced.)"""
 import ctypes as C
 import os
 import sys
@@ -50,7 +52,6 @@ if os.path.exists(prev):
     builds.append(("prev", other(prev)))
 if os.path.exists(exp):
     builds.append(("exp", other(exp)))
-    builds.append(("exp+cache", other(exp, {"MTGPU_PLAN_CACHE": "1"})))
 if compact:
     rec = m.pack_records(w["mv"])
     d_in = torch.from_numpy(rec.view(np.uint8).reshape(-1).copy()).to(dev).repeat(w["reps"])[: w["n_records"] * 8].contiguous()
