@@ -1161,6 +1161,53 @@ def test_scratch_pool_stats_and_trim(gpu_scanner_factory):
     assert s.stats()["staging_device_bytes"] >= 40 * len(mv)
 
 
+def test_trim_while_other_threads_scan(gpu_scanner_factory):
+    """mtgpu_trim is "safe at any time, from any thread": two threads scan banded batches (each launch holds a scratch
+    block: work list + spill queue) on their own streams while a third trims the context's scratch ring in a loop —
+    blocks in use stay, idle ones go, launches that follow allocate again; every flag right, and the ring ends empty."""
+    import threading
+    import torch
+    p, s = _fine_shipped_env_scanner(gpu_scanner_factory)            # 960x540, 2 spill bands
+    spec = synth.spec_4k_fine_dense(seed=5)
+    spec.events = [synth.Event(1, 5, 300, 200, 5, 4, 7, 1)]
+    errors, lock, stop = [], threading.Lock(), threading.Event()
+
+    def scan(w):
+        try:
+            mv, off, pts, sd = synth.gen_stream(spec, 4 + w, first_frame=w)
+            want = ob.scan_frames(p, mv, off, sd)
+            st = torch.cuda.Stream()
+            d_mv = torch.from_numpy(mv.view(np.uint8).copy()).cuda()
+            d_off = torch.from_numpy(off.astype(np.int64)).cuda()
+            d_sd = torch.from_numpy(sd).cuda()
+            torch.cuda.synchronize()
+            for _ in range(25):
+                got = s.check_frames_device(d_mv, d_off, d_sd, stream=st.cuda_stream)
+                st.synchronize()
+                assert np.array_equal(got.cpu().numpy(), want)
+        except BaseException as e:          # noqa: BLE001 - reported to the main thread
+            with lock:
+                errors.append((w, repr(e)))
+
+    def trim():
+        while not stop.is_set():
+            s.trim()
+
+    threads = [threading.Thread(target=scan, args=(w,)) for w in range(2)]
+    tt = threading.Thread(target=trim)
+    tt.start()
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    stop.set()
+    tt.join()
+    assert not errors, errors
+    torch.cuda.synchronize()
+    s.trim()
+    assert s.stats()["pool_reserved_bytes"] == 0
+
+
 def test_plain_c_example(tmp_path):
     """examples/scan_example.c: the ABI consumed from plain C (gcc), end to end on the GPU."""
     import os
