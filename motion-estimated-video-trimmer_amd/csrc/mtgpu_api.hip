@@ -639,7 +639,7 @@ extern "C" int mtgpu_debug_set_phase_times(void *p) {      // developer build on
 extern "C" {
 
 const char *mtgpu_version(void) {
-  return mtgpu::kExperiments ? "mtgpu 0.5 (gfx950 MV scan + segment merge) +experiments" : "mtgpu 0.5 (gfx950 MV scan + segment merge)";
+  return mtgpu::kExperiments ? "mtgpu 0.6 (gfx950 MV scan + segment merge) +experiments" : "mtgpu 0.6 (gfx950 MV scan + segment merge)";
 }
 
 const char *mtgpu_last_error(void) { return g_err; }
