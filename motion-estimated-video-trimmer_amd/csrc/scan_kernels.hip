@@ -389,7 +389,10 @@ __device__ __forceinline__ void bump_cells_wave(unsigned int *cnt, unsigned int 
 
 // Threshold + cell mapping + vote for one record (src/motion_scanner.cpp:246-267).
 // [t0,t1) = grid rows this tile tracks.
-template <int FB, int MODE, bool SPILL>
+// DENSE: try the dense-wave shortcut first — only the main streaming loop over 40-byte records asks for it (whole
+// waves, one record per lane in stream order; the compact loop holds two records per lane, head and tail calls run
+// under divergence): compiled into every call site it tripled the library's code size.
+template <int FB, int MODE, bool SPILL, bool DENSE = false>
 __device__ __forceinline__ void vote(const MvFields m, const ScanK &k, int t0, int t1,
                                      unsigned int *cnt, const SpillQ &sq) {
   const unsigned int dx = (unsigned int)(m.dst_x - m.src_x);   // |dx| <= 65535
@@ -417,7 +420,7 @@ __device__ __forceinline__ void vote(const MvFields m, const ScanK &k, int t0, i
     if (any == 0ull) return;
     const int lane = (int)(threadIdx.x & 63u);
     const unsigned int key = in ? (((unsigned int)gy << 15) | (unsigned int)gx) : 0xffffffffu;   // gx, gy < 32768
-    if constexpr (MODE == MODE_UNARY && FB >= 2 && FB <= 8) {
+    if constexpr (DENSE && MODE == MODE_UNARY && FB >= 2 && FB <= 8) {
       // DENSE wave instruction — all 64 records vote and fall, in order, into consecutive cells of one grid row, R = 1, 2
       // or 4 records per cell: what dense motion (a camera pan) looks like in raster-ordered records.  The general path
       // below (runs, queue segments: a shuffle, eight ballots and 64-bit bit-scans per wave instruction) makes such input
@@ -784,7 +787,7 @@ __device__ __forceinline__ void scan_item(
             // (the scheduler sinks loads 2..UNROLL below the wait for load 1; forcing them up front with
             //  a sched_barrier measured -1..-2 % here, +7 % in the compact loop above: left as it is)
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) vote<FB, MODE, SPILL>(decode(d[u]), k, t0, t1, cnt, sq);
+            for (int u = 0; u < UNROLL; ++u) vote<FB, MODE, SPILL, true>(decode(d[u]), k, t0, t1, cnt, sq);
           }
         }
         if (i < n) {
