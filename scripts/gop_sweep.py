@@ -63,11 +63,10 @@ def other_library(path, env=None):
 
 
 builds = [("new", m.MotionScanner(params, 0))]
-for spec_ in [x for x in os.environ.get("GOP_GROUPS", "").split(",") if x]:       # e.g. "1,2,2p,8p": MTGPU_GROUP [+ the work list]
+for spec_ in [x for x in os.environ.get("GOP_GROUPS", "").split(",") if x]:       # e.g. "1,2,8": MTGPU_GROUP (a trailing "p" once forced the work list)
     os.environ["MTGPU_GROUP"] = spec_.rstrip("p")
     builds.append((f"g{spec_}", m.MotionScanner(params, 0)))
     os.environ.pop("MTGPU_GROUP")
-    pass
 prev = os.environ.get("GOP_PREV_LIB") or os.path.join(ROOT, "scripts", "libmtgpu_prev.so")
 if os.path.exists(prev) and os.environ.get("GOP_PREV", "1") != "0":
     builds.append(("prev", other_library(prev)))

@@ -19,11 +19,10 @@ compact = len(sys.argv) > 3 and sys.argv[3] == "compact"
 dev = torch.device("cuda", 0)
 w = bench.build_workload(wl, "code_defaults", frames, 60, 1000, dev)
 builds = [("auto", w["scanner"])]
-for g in os.environ.get("GROUPS", "1,2,4").split(","):      # "2p" = two frames per workgroup over the work list
+for g in os.environ.get("GROUPS", "1,2,4").split(","):      # (a trailing "p", as in the logs of round 6, once forced the work list)
     os.environ["MTGPU_GROUP"] = g.rstrip("p")
     builds.append((f"group{g}", m.MotionScanner(w["params"], 0)))
     os.environ.pop("MTGPU_GROUP")
-    pass
 if compact:
     rec = m.pack_records(w["mv"])
     d_in = torch.from_numpy(rec.view(np.uint8).reshape(-1).copy()).to(dev).repeat(w["reps"])[: w["n_records"] * 8].contiguous()
